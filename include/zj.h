@@ -1,0 +1,184 @@
+/*
+ * zj.h -- C ABI of the MI355X baseline-JPEG decode path.
+ *
+ * The reference (crate `zen-jpeg`) has no FFI boundary of its own: its whole product is
+ * `Decoder::decode()` (src/decoder.rs:330-651).  This header is the boundary a maintainer would
+ * bind from Rust: the host keeps the marker walk and the DQT / DHT / SOF0 / SOS parsing
+ * (src/decoder.rs:347-642) and hands the parsed state to the device at the two places where the
+ * reference starts its hot loops -- the SOS arm (src/decoder.rs:366-390) and `to_rgb`
+ * (src/decoder.rs:644-646).  Plain pointers and sizes only; nothing here unwinds or aborts.
+ *
+ * Threading: a zj_ctx is bound to one GPU and must be used from one thread at a time; one ctx
+ * (and one process or host thread) per GPU.  Calls on distinct contexts are independent.
+ * Ownership: the caller owns every pointer it passes; inputs are borrowed for the duration of
+ * the call that takes them (zj_batch_create copies what it needs to the device); outputs are
+ * caller-allocated.  The library owns all device scratch inside zj_ctx / zj_batch.
+ */
+#ifndef ZJ_H
+#define ZJ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- return codes of the functions below (0 = success, negative = failure) ---- */
+#define ZJ_OK 0
+#define ZJ_E_INVALID (-1)     /* bad argument                                                       */
+#define ZJ_E_FORMAT (-2)      /* malformed container (the reference panics: src/decoder.rs:358 ...) */
+#define ZJ_E_UNSUPPORTED (-3) /* valid JPEG outside the path (progressive, 16-bit DQT, 1 component) */
+#define ZJ_E_DEVICE (-4)      /* HIP runtime error or no usable GPU; see zj_last_error              */
+#define ZJ_E_NOMEM (-5)
+#define ZJ_E_IO (-6)          /* counterpart of DecodeError::Io (src/error.rs:4-6)                  */
+
+/* ---- per-image status word (bit set; 0 = decoded cleanly).  Each bit replaces one of the
+ *      reference's panics on malformed entropy data. ---- */
+#define ZJ_ST_BAD_CODE 1u      /* bit pattern that is no code of the table (src/ec.rs:27,47 OOB)   */
+#define ZJ_ST_COEF_OVERFLOW 2u /* run past coefficient 63            (src/decoder.rs:228 OOB)      */
+#define ZJ_ST_TRUNCATED 4u     /* entropy data ended early           (src/decoder.rs:197,222)      */
+#define ZJ_ST_UNSUPPORTED 8u   /* image rejected at plan time, nothing decoded                      */
+
+/* One DHT table as it appears in the file: BITS and HUFFVAL (src/decoder.rs:497-513). */
+typedef struct zj_huff {
+    uint8_t counts[16];
+    uint8_t symbols[256];
+} zj_huff;
+
+/*
+ * One parsed image = the state the reference holds when it reaches the SOS arm:
+ * dimensions (src/decoder.rs:570-583), quantisation tables in file (zig-zag) order (:453),
+ * Huffman tables indexed [table id][0 = AC, 1 = DC] (:553), plus what the reference reads and
+ * drops: sampling factors (:612-613), SOS selectors (:368-370) and the restart interval.
+ * `scan` is the entropy-coded segment exactly as stored: stuffed bytes and RSTn markers
+ * included, from the first byte after the SOS header up to (not including) the terminating
+ * marker.  HOST memory.
+ */
+typedef struct zj_image {
+    const uint8_t *scan;
+    size_t scan_len;
+    uint16_t width, height;
+    uint8_t ncomp;       /* 3 */
+    uint8_t hsamp[3];    /* luma 1 or 2, chroma 1 */
+    uint8_t vsamp[3];
+    uint8_t tq[3];       /* component -> quantisation table id */
+    uint8_t td[3];       /* component -> DC table id (0 or 1)  */
+    uint8_t ta[3];       /* component -> AC table id (0 or 1)  */
+    uint16_t restart_interval; /* MCUs per restart interval, 0 = no restart markers */
+    const uint8_t *qt[4];      /* 64 bytes each, zig-zag order; NULL if undefined    */
+    const zj_huff *ht[2][2];   /* [id][0 = AC, 1 = DC]; NULL if undefined            */
+} zj_image;
+
+/* Result of the host-side container parse; owns copies of the tables, borrows the file bytes. */
+typedef struct zj_parsed {
+    zj_image image; /* image.scan points into the caller's file buffer */
+    uint8_t qt_store[4][64];
+    zj_huff ht_store[2][2];
+    uint32_t n_restart_markers; /* RSTn markers found inside the scan */
+} zj_parsed;
+
+/* Where an output pointer lives. */
+#define ZJ_MEM_HOST 0
+#define ZJ_MEM_DEVICE 1
+
+/* Outputs of one image.  Any pointer may be NULL.
+ *   rgb    interleaved RGB8, rows `rgb_stride` bytes apart (0 = 3*width): the payload of the
+ *          reference's out.ppm (src/decoder.rs:644-648)
+ *   qcoef  int16 [nblocks][64], zig-zag order, before dequantisation, DC after prediction;
+ *          blocks in scan order (MCU-major; inside an MCU luma blocks row by row, then Cb, Cr)
+ *   dqcoef int16 [nblocks][64], natural order, dequantised: the reference's `blocks`
+ *          (src/decoder.rs:387) */
+typedef struct zj_output {
+    uint8_t *rgb;
+    size_t rgb_stride;
+    int16_t *qcoef;
+    int16_t *dqcoef;
+    int mem; /* ZJ_MEM_HOST or ZJ_MEM_DEVICE, applies to all three pointers */
+} zj_output;
+
+typedef struct zj_ctx zj_ctx;
+typedef struct zj_batch zj_batch;
+
+/* ---------------------------------------------------------------- host side (no GPU needed) */
+
+/* Container parse: replaces the marker loop of Decoder::decode (src/decoder.rs:347-642) for
+ * everything except the SOS hot loop.  Accepts every APPn / COM (skipped by length), several
+ * tables per DQT / DHT segment, DRI.  Returns ZJ_OK, ZJ_E_FORMAT or ZJ_E_UNSUPPORTED. */
+int zj_parse(const uint8_t *file, size_t len, zj_parsed *out);
+
+/* Geometry helpers derived from a parsed image. */
+uint32_t zj_image_blocks(const zj_image *img);       /* number of 8x8 blocks in scan order */
+uint32_t zj_image_mcus(const zj_image *img);
+
+/* Byte offsets (relative to img->scan) at which restart intervals begin: entry 0 is 0, entry k
+ * is the byte after the k-th RSTn marker.  Writes at most `cap` entries, returns the number of
+ * intervals found.  Used to cut one huge restart-marked image into per-GPU bands. */
+size_t zj_restart_offsets(const zj_image *img, size_t *offsets, size_t cap);
+
+/* Build the sub-image that covers MCU rows [row0, row0 + nrows) of `img`.  Requires restart
+ * intervals that tile MCU rows exactly ((mcus per row) % restart_interval == 0, or an interval
+ * of whole rows).  `band` borrows img's tables and points into img's scan; its height is the band's pixel
+ * height (clipped to the image).  Returns ZJ_OK or ZJ_E_INVALID. */
+int zj_image_band(const zj_image *img, uint32_t row0, uint32_t nrows, zj_image *band);
+
+/* PPM writer: header as src/decoder.rs:580, payload as :648. */
+int zj_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb, size_t stride);
+
+/* ---------------------------------------------------------------- device side */
+
+int zj_device_count(void);
+
+/* Create a context on GPU `device`.  `stream` is a hipStream_t to launch on (NULL = a stream
+ * the context creates and owns).  Returns NULL on failure. */
+zj_ctx *zj_create(int device, void *stream);
+void zj_destroy(zj_ctx *ctx);
+const char *zj_last_error(zj_ctx *ctx);
+
+/* Tuning knob: bits per bitstream subsequence handed to one lane of the Huffman stage (a power of
+ * two, 256..8192; 0 = choose from the batch size). */
+#define ZJ_FLAG_SUBSEQ_BITS(b) ((uint32_t)(b))
+
+/* Plan a batch: validates the images, builds the device tables, uploads the scans, allocates all
+ * scratch and the coefficient arena.  Everything the decode call needs is resident in HBM when
+ * this returns.  Images that are unsupported keep a slot and report ZJ_ST_UNSUPPORTED. */
+zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *imgs, size_t n, uint32_t flags);
+void zj_batch_destroy(zj_batch *b);
+
+/* The hot path: stage 1 (unstuff, self-synchronising parallel Huffman decode, DC prefix scan)
+ * -> quantised coefficients in the batch's arena; stage 2+3 (dequantise, 8x8 IDCT, chroma
+ * upsample, YCbCr->RGB, store) -> rgb[i].  rgb[i] are DEVICE pointers (NULL entries skip stage
+ * 2+3 for that image); stride[i] in bytes (NULL or 0 = 3*width).  Asynchronous on the context's
+ * stream; allocates nothing. */
+int zj_batch_decode(zj_batch *b, uint8_t *const *rgb, const size_t *stride);
+
+/* Wait for the stream, then copy out the per-image status words (n entries).  If the device
+ * reported that subsequence synchronisation had not converged, this call reruns the decode with
+ * the exhaustive fix-up loop before returning (never observed on real streams). */
+int zj_batch_finish(zj_batch *b, uint32_t *status);
+
+/* Device pointer to image i's quantised coefficients inside the arena (valid until destroy). */
+const int16_t *zj_batch_qcoef(zj_batch *b, size_t i);
+/* Copy image i's coefficients out: zig-zag quantised and/or natural-order dequantised. */
+int zj_batch_export_coef(zj_batch *b, size_t i, int16_t *qcoef, int16_t *dqcoef, int mem);
+
+/* Per-kernel timing: when enabled, zj_batch_decode brackets every kernel with events on the
+ * context's stream; zj_batch_kernel_times waits and returns milliseconds of the last decode call
+ * in the order of zj_kernel_name(0..ZJ_NUM_KERNELS-1). */
+#define ZJ_NUM_KERNELS 9
+int zj_batch_set_profiling(zj_batch *b, int enable);
+int zj_batch_kernel_times(zj_batch *b, float *ms /* ZJ_NUM_KERNELS */);
+const char *zj_kernel_name(int k);
+
+/* Byte counts of the batch for roofline accounting: scan bytes as stored (S), coefficient bytes
+ * (C = blocks * 128), RGB bytes (P = 3 * w * h), summed over the supported images. */
+int zj_batch_bytes(zj_batch *b, uint64_t *scan_bytes, uint64_t *coef_bytes, uint64_t *rgb_bytes, uint64_t *pixels);
+
+/* One-shot convenience with the reference's call shape (parse -> decode -> pixels):
+ * plan + decode + finish + copy-out + destroy.  outs[i].mem selects host or device outputs. */
+int zj_decode_batch(zj_ctx *ctx, const zj_image *imgs, size_t n, const zj_output *outs, uint32_t *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZJ_H */

@@ -1,0 +1,281 @@
+// zj_core.h -- data layout and per-lane entropy-decode primitives shared by the HIP kernels and
+// by the host-side table builder.  Everything here is plain integer code that compiles for the
+// device (hipcc) and for the host (g++), so the same functions can be exercised lane by lane on a
+// CPU in the tests.
+//
+// Arithmetic contract (what "identical to the reference" means for stage 1):
+//   * canonical Huffman decode of one symbol            -- src/ec.rs:19-49
+//   * EXTEND / sign_code                                -- src/ec.rs:52-59
+//   * block walk: DC symbol, AC run/size loop, EOB, stop at index 64 -- src/decoder.rs:186-235
+// For every stream the reference decodes without panicking, any correct canonical decoder yields
+// the same symbols, so the lookup tables below are free to be organised for the GPU.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ZJ_HD __attribute__((host)) __attribute__((device)) inline __attribute__((always_inline))
+#else
+#define ZJ_HD inline
+#endif
+
+// ---- lookup-table format -------------------------------------------------------------------
+// A table set holds four tables in the order DC id 0, DC id 1, AC id 0, AC id 1.  Each table is
+// ZJ_TBL_ENTRIES uint16 entries: a first level indexed by the next ZJ_L1_BITS bits of the stream,
+// followed by second-level sub-tables for longer codes.
+//   entry, bit 15 clear:  [12:8] code length (0 = no such code), [7:0] symbol
+//   entry, bit 15 set  :  first level only: [14:12] nb = extra index bits (1..7), [8:0] offset of the
+//                         sub-table inside the second level; nb == 0: the table does not fit the
+//                         second level, use the canonical search (ZjCanon) instead.
+#define ZJ_L1_BITS 9
+#define ZJ_L1_SIZE 512
+#define ZJ_L2_SIZE 256
+#define ZJ_TBL_ENTRIES (ZJ_L1_SIZE + ZJ_L2_SIZE)
+#define ZJ_SET_ENTRIES (4 * ZJ_TBL_ENTRIES)
+
+// Canonical description of one table, used by the rare fallback path only.
+struct ZjCanon {
+    uint16_t ncode[17];   // number of codes of length l (index 1..16)
+    uint16_t mincode[17]; // smallest code of length l (right-aligned)
+    uint16_t valptr[17];  // index of its symbol
+    uint8_t symbols[256];
+    uint16_t nsym;
+};
+
+// ---- device-resident descriptors -----------------------------------------------------------
+struct ZjImgDev {
+    uint32_t w, h;
+    uint32_t mcux, mcuy;
+    uint32_t hs, vs, bpm;   // luma sampling factors, blocks per MCU (hs*vs + 2)
+    uint32_t ri_blocks;     // blocks per restart segment (0 = one segment)
+    uint32_t first_seg, nseg;
+    uint32_t first_sub;     // first global subsequence index (multiple of 256)
+    uint32_t nsub;          // subsequence slots of this image (multiple of 256)
+    uint32_t first_block;   // first global block index (multiple of 256)
+    uint32_t nblocks;
+    uint32_t lut_set;       // index into the table-set arena
+    uint32_t dcsel;         // bit k: DC table id of block k inside the MCU
+    uint32_t acsel;         // bit k: AC table id of block k inside the MCU
+    uint32_t compsel;       // 2 bits per block k: component of block k
+    uint32_t qt_off[3];     // byte offsets of the three components' quantisation tables (64 B each)
+    uint32_t first_strip;   // first global strip index of stage 2
+    uint32_t strips_x;      // strips per MCU row
+    uint32_t flags;         // bit 0: supported
+    uint32_t pad0;
+};
+
+struct ZjSegDev {
+    uint64_t raw_begin, raw_end; // byte range in the raw (stuffed) scan arena
+    uint64_t out_off;            // byte offset of the unstuffed stream in its arena (multiple of 16)
+    uint32_t out_cap;            // bytes reserved there (multiple of 16, >= payload + 16, zero filled)
+    uint32_t img;
+    uint32_t first_sub;          // global subsequence index of the segment's first lane (multiple of 64)
+    uint32_t nsub;               // subsequences that can hold payload: ceil(raw bits / subsequence bits)
+    uint32_t first_block;        // global block index of the segment's first block
+    uint32_t nblocks;            // blocks coded in this segment
+};
+
+// Packed per-subsequence record ("s_info"): where the decoder stands when it crosses the end of
+// the subsequence, and how many blocks began inside it.
+//   [5:0]   overflow: bits the last symbol reaches past the nominal end (0..32)
+//   [9:6]   index of the current block inside its MCU
+//   [15:10] zig-zag index inside the block (0 = a DC symbol comes next)
+//   [31:16] blocks whose DC symbol starts inside this subsequence
+#define ZJ_INFO_STATE_MASK 0xFFFFu
+
+struct ZjState {
+    uint32_t p; // bit position inside the segment's unstuffed stream
+    uint32_t b; // block inside the MCU
+    uint32_t z; // zig-zag index, 0 = at a block start
+};
+
+ZJ_HD uint32_t zj_pack_info(const ZjState &s, uint32_t nominal_end, uint32_t nblk)
+{
+    uint32_t o = s.p > nominal_end ? s.p - nominal_end : 0u;
+    return (o & 63u) | (s.b << 6) | (s.z << 10) | (nblk << 16);
+}
+ZJ_HD ZjState zj_unpack_state(uint32_t info, uint32_t nominal_end)
+{
+    ZjState s;
+    s.p = nominal_end + (info & 63u);
+    s.b = (info >> 6) & 15u;
+    s.z = (info >> 10) & 63u;
+    return s;
+}
+
+// ---- bit reader over the unstuffed stream ----------------------------------------------------
+ZJ_HD uint32_t zj_bswap32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bswap32(x);
+#else
+    return (x >> 24) | ((x >> 8) & 0xff00u) | ((x << 8) & 0xff0000u) | (x << 24);
+#endif
+}
+
+// MSB-first reader.  `base` is the 4-byte aligned start of a segment's unstuffed stream; the arena
+// keeps at least 16 readable, zero-filled bytes behind every segment, which reproduces the
+// reference's zero padding at the end of data (src/bitstream.rs:80-84).
+struct ZjBits {
+    const uint32_t *base;
+    uint32_t widx; // next word to load
+    uint64_t buf;  // left-aligned window
+    int32_t cnt;   // valid bits in buf, always > 32 between calls
+
+    ZJ_HD void init(const uint32_t *b, uint32_t bitpos)
+    {
+        base = b;
+        widx = bitpos >> 5;
+        uint64_t w0 = zj_bswap32(base[widx]), w1 = zj_bswap32(base[widx + 1]);
+        widx += 2;
+        uint32_t sh = bitpos & 31u;
+        buf = ((w0 << 32) | w1) << sh;
+        cnt = 64 - (int32_t)sh;
+    }
+    ZJ_HD uint32_t top32() const { return (uint32_t)(buf >> 32); }
+    ZJ_HD void skip(uint32_t n) // n <= 32
+    {
+        buf <<= n;
+        cnt -= (int32_t)n;
+        if (cnt <= 32) {
+            uint64_t w = zj_bswap32(base[widx++]);
+            buf |= w << (32 - cnt);
+            cnt += 32;
+        }
+    }
+};
+
+// ---- one Huffman symbol ----------------------------------------------------------------------
+// Canonical search, the textbook form of src/ec.rs:30-47 (first length whose code range holds the
+// window).  Returns an entry in the short format, 0 if the window starts no code.
+ZJ_HD uint32_t zj_canon_lookup(const ZjCanon *c, uint32_t top32)
+{
+    uint32_t w16 = top32 >> 16;
+    for (uint32_t l = 1; l <= 16; l++) {
+        uint32_t nc = c->ncode[l], code = w16 >> (16 - l);
+        if (nc != 0 && code >= c->mincode[l] && code < (uint32_t)c->mincode[l] + nc) {
+            uint32_t idx = c->valptr[l] + (code - c->mincode[l]);
+            return (l << 8) | c->symbols[idx & 255u];
+        }
+    }
+    return 0;
+}
+
+// tbl: one table (ZJ_TBL_ENTRIES entries).  Returns [12:8] length, [7:0] symbol; length 0 = invalid.
+ZJ_HD uint32_t zj_lookup(const uint16_t *tbl, const ZjCanon *canon, uint32_t top32)
+{
+    uint32_t e = tbl[top32 >> (32 - ZJ_L1_BITS)];
+    if (e & 0x8000u) {
+        uint32_t nb = (e >> 12) & 7u;
+        if (nb == 0) return zj_canon_lookup(canon, top32);
+        e = tbl[ZJ_L1_SIZE + (e & 0x1FFu) + ((top32 >> (32 - ZJ_L1_BITS - nb)) & ((1u << nb) - 1u))];
+    }
+    return e;
+}
+
+// src/ec.rs:52-59 with the i16 wrap and masked shift of a --release build.
+ZJ_HD int32_t zj_extend(uint32_t nbits, uint32_t v)
+{
+    if (((v << 1) >> nbits) != 0) return (int32_t)(int16_t)v;
+    int32_t maxv = (int32_t)(int16_t)((1u << (nbits & 15u)) - 1u);
+    return (int32_t)(int16_t)((int32_t)(int16_t)v - maxv);
+}
+
+struct ZjSel { // table selectors of the image a lane works on
+    uint32_t bpm, dcsel, acsel;
+};
+
+// What a span decode records besides the state.
+struct ZjIndexOut {
+    uint32_t *blockpos; // [segment block] bit position of the block's DC symbol
+    int16_t *dcdiff;    // [segment block] decoded DC difference
+    uint32_t g;         // next segment-relative block index
+    uint32_t glimit;    // blocks coded in the segment
+};
+
+// Walk the symbols that START inside [st.p, end) -- the serial loop of src/decoder.rs:194-235 seen
+// as a state machine over (bit position, block in MCU, zig-zag index).  Returns the number of
+// blocks that began.  With INDEX it also records where each block begins and its DC difference.
+template <bool INDEX>
+ZJ_HD uint32_t zj_decode_span(const uint32_t *stream, const uint16_t *lut, const ZjCanon *canon, const ZjSel &sel,
+                              ZjState &st, uint32_t end, ZjIndexOut *io)
+{
+    uint32_t nblk = 0;
+    if (st.p >= end) return 0;
+    ZjBits bits;
+    bits.init(stream, st.p);
+    uint32_t p = st.p, b = st.b, z = st.z;
+    while (p < end) {
+        uint32_t top = bits.top32();
+        bool isdc = (z == 0);
+        uint32_t t = isdc ? ((sel.dcsel >> b) & 1u) : (2u + ((sel.acsel >> b) & 1u));
+        uint32_t e = zj_lookup(lut + t * ZJ_TBL_ENTRIES, canon ? canon + t : nullptr, top);
+        uint32_t len = (e >> 8) & 31u, sym = e & 255u;
+        uint32_t s = isdc ? sym : (sym & 15u);
+        if (s > 16u) s = 16u;
+        uint32_t tot = len + s;
+        if (len == 0) tot = 1; // no such code: keep moving, the write pass reports it
+        if (isdc) {
+            if (INDEX) {
+                if (io->g < io->glimit) {
+                    uint32_t v = s ? ((top << len) >> (32 - s)) : 0u;
+                    io->blockpos[io->g] = p;
+                    io->dcdiff[io->g] = (int16_t)zj_extend(s, v);
+                }
+                io->g++;
+            }
+            nblk++;
+            z = 1;
+        } else if (sym == 0) {
+            z = 0;
+            b++;
+        } else {
+            z += (sym >> 4) + 1u;
+            if (z >= 64u) { z = 0; b++; }
+        }
+        if (b >= sel.bpm) b = 0;
+        bits.skip(tot);
+        p += tot;
+    }
+    st.p = p; st.b = b; st.z = z;
+    return nblk;
+}
+
+// Decode one block that begins at bit `p0` into row[0..63] (zig-zag order, already zeroed).
+// The DC value comes from the prefix scan; only its bits are skipped here.  Returns status bits and
+// the bit position behind the block.
+ZJ_HD uint32_t zj_decode_block(const uint32_t *stream, const uint16_t *lut, const ZjCanon *canon, uint32_t tdc,
+                               uint32_t tac, uint32_t p0, int16_t dc, int16_t *row, uint32_t *pend)
+{
+    ZjBits bits;
+    bits.init(stream, p0);
+    uint32_t p = p0, status = 0;
+    {
+        uint32_t top = bits.top32();
+        uint32_t e = zj_lookup(lut + tdc * ZJ_TBL_ENTRIES, canon ? canon + tdc : nullptr, top);
+        uint32_t len = (e >> 8) & 31u, s = e & 255u;
+        if (len == 0 || s > 16u) { *pend = p; return 1u; /* ZJ_ST_BAD_CODE */ }
+        bits.skip(len + s);
+        p += len + s;
+    }
+    row[0] = dc;
+    const uint16_t *ac = lut + (2u + tac) * ZJ_TBL_ENTRIES;
+    const ZjCanon *cac = canon ? canon + 2u + tac : nullptr;
+    uint32_t z = 1;
+    while (z < 64u) {
+        uint32_t top = bits.top32();
+        uint32_t e = zj_lookup(ac, cac, top);
+        uint32_t len = (e >> 8) & 31u, sym = e & 255u;
+        if (len == 0) { status |= 1u; break; }
+        uint32_t s = sym & 15u;
+        p += len + s;
+        if (sym == 0) break; // EOB
+        z += sym >> 4;
+        if (z >= 64u) { status |= 2u; /* ZJ_ST_COEF_OVERFLOW */ break; }
+        uint32_t v = s ? ((top << len) >> (32 - s)) : 0u;
+        row[z] = (int16_t)zj_extend(s, v);
+        z++;
+        bits.skip(len + s);
+    }
+    *pend = p;
+    return status;
+}

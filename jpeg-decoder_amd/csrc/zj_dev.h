@@ -1,0 +1,59 @@
+// zj_dev.h -- kernel parameter block and launch geometry shared by zj_kernels.hip and zj_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "zj_core.h"
+
+// Kernel order used by the per-kernel timing interface.
+enum {
+    ZJ_K_UNSTUFF = 0,
+    ZJ_K_SYNC,
+    ZJ_K_FIX,
+    ZJ_K_SCAN,
+    ZJ_K_INDEX,
+    ZJ_K_DCSCAN,
+    ZJ_K_WRITE,
+    ZJ_K_IDCT_RGB,
+    ZJ_K_TOTAL, // whole decode call
+};
+
+struct ZjParams {
+    const ZjImgDev *imgs;
+    const ZjSegDev *segs;
+    const uint8_t *raw;         // stuffed scans, every image 16-byte aligned
+    uint8_t *ust;               // unstuffed segments
+    uint32_t *seg_payload_bits; // [seg] bits of unstuffed payload
+    uint32_t *seg_found;        // [seg] blocks found in the payload
+    const uint32_t *chunk_seg;  // [chunk of 64 subsequences] segment or ZJ_NONE
+    uint32_t *sinfo;            // [subsequence] packed record
+    uint32_t *base;             // [subsequence] blocks that begin earlier in the segment
+    uint32_t *blockpos;         // [block] bit position of the block in its segment's stream
+    int16_t *dcdiff;            // [block]
+    int16_t *dcabs;             // [block]
+    int16_t *qcoef;             // [block][64] zig-zag, quantised: the stage seam
+    const uint16_t *luts;       // [table set][ZJ_SET_ENTRIES]
+    const ZjCanon *canons;      // [table set][4]
+    const uint8_t *qts;         // quantisation tables, 64 bytes each, zig-zag order
+    const uint32_t *blk256_img; // [block / 256] image
+    const uint32_t *strip_img;  // [strip] image
+    uint32_t *status;           // [image]
+    uint32_t *flags;            // [0] fix pass ran through a whole chunk, [1] record chain inconsistent
+    uint8_t *const *rgb;        // [image] device pointers
+    const size_t *rgb_stride;   // [image]
+    uint32_t nchunks;
+    uint32_t subbits;
+};
+
+struct ZjLaunch {
+    uint32_t nseg, nchunks, nblk256, nstrips;
+    int fix_iters;
+};
+
+extern "C" {
+void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream_t st, hipEvent_t *ev);
+void zj_launch_fix_only(const ZjParams &P, const ZjLaunch &L, hipStream_t st);
+void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipStream_t st);
+void zj_launch_stage2(const ZjParams &P, const ZjLaunch &L, hipStream_t st, hipEvent_t *ev);
+void zj_launch_dequant(const ZjParams &P, uint32_t ii, uint32_t nblocks, int16_t *dst, hipStream_t st);
+}

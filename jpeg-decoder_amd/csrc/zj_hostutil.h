@@ -1,0 +1,12 @@
+// zj_hostutil.h -- host-internal helpers shared by zj_host.cpp and zj_api.hip.
+#pragma once
+#include "../../include/zj.h"
+#include "zj_core.h"
+
+// True if the image is inside the decode path (3 components, luma sampling 1..2, chroma 1x1,
+// tables present).
+bool zj_image_supported(const zj_image *im);
+
+// Build one device lookup table (ZJ_TBL_ENTRIES entries) and its canonical description from a DHT
+// table.  Returns false if the table is not a prefix code.
+bool zj_build_table(const zj_huff *h, uint16_t *tbl, ZjCanon *canon);

@@ -1,0 +1,665 @@
+// zj_kernels.hip -- gfx950 kernels of the baseline-JPEG decode path.
+//
+// Stage 1 (entropy decode; replaces the serial MCU loop of src/decoder.rs:366-390 with
+// src/ec.rs and src/bitstream.rs underneath):
+//   k0_unstuff   FF00 -> FF compaction of every entropy-coded segment      (src/bitstream.rs:37-50)
+//   k1a_sync     one lane per fixed-size bitstream subsequence, one wavefront per 64 of them;
+//                lanes decode from a guessed state and keep decoding into their neighbours'
+//                subsequences until their state meets the recorded one (self-synchronisation)
+//   k1b_fix      stitches consecutive wavefront chunks the same way, one lane per chunk boundary
+//   k1s_scan     exclusive prefix sum of blocks-per-subsequence inside each segment
+//   k1i_index    second walk from the now-known states: where every block begins and its DC
+//                difference; verifies the chain of recorded states
+//   k1d_dcscan   DC predictor = wrapping-i16 prefix sum per component      (src/decoder.rs:199-200)
+//   k1w_write    one lane per block: decode the block into an LDS tile, store 64 blocks coalesced
+// Stage 2+3 (src/decoder.rs:179-184 dequantize, :137-146 de-zigzag, src/dct.rs IDCT,
+// src/decoder.rs:265-320 colour + store):
+//   k2_idct_rgb  LDS-staged column pass / row pass, chroma replication, YCbCr->RGB, coalesced store
+// Everything floating point keeps the reference's operation order; the file is compiled with
+// -ffp-contract=off so that only the explicit fmaf chains of the IDCT are fused (src/dct.rs:95).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "zj_core.h"
+#include "zj_dev.h"
+
+#define ZJ_NONE 0xFFFFFFFFu
+
+// ---------------------------------------------------------------------------------- helpers
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+// Inclusive scan over a workgroup of NW waves.  `wsum` is NW+1 words of LDS.  Returns the inclusive
+// value; *total receives the workgroup sum.  Contains two barriers.
+template <int NW>
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t *wsum, uint32_t *total)
+{
+    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v, lane);
+    __syncthreads();
+    if (lane == 63u) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        uint32_t s = wsum[w];
+        if ((uint32_t)w < wave) off += s;
+        tot += s;
+    }
+    *total = tot;
+    return inc + off;
+}
+
+__device__ __forceinline__ bool sub_active(const ZjSegDev &sg, uint32_t q, uint32_t subbits, uint32_t payload_bits)
+{
+    return q < sg.nsub && (uint64_t)q * subbits < (uint64_t)payload_bits;
+}
+
+__device__ __forceinline__ uint32_t sub_end(uint32_t q, uint32_t subbits, uint32_t payload_bits)
+{
+    uint64_t e = (uint64_t)(q + 1u) * subbits;
+    return e < payload_bits ? (uint32_t)e : payload_bits;
+}
+
+__device__ __forceinline__ void load_lut_to_lds(uint16_t *lds, const uint16_t *src)
+{
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d4 = reinterpret_cast<uint4 *>(lds);
+    for (uint32_t i = threadIdx.x; i < ZJ_SET_ENTRIES * 2 / 16; i += blockDim.x) d4[i] = s4[i];
+}
+
+// ---------------------------------------------------------------------------------- k0: unstuff
+// One wavefront per segment.  Walks the raw bytes in 1 KiB tiles (16 bytes per lane), drops every 00
+// that follows an FF, and appends the kept bytes to an LDS buffer that is flushed in aligned
+// 16-byte pieces.  Writes the payload length and zero-fills the rest of the segment's slot.
+__global__ __launch_bounds__(64) void zj_k0_unstuff(ZjParams P)
+{
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    const ZjSegDev sg = P.segs[s];
+    __shared__ __attribute__((aligned(16))) uint8_t buf[1024 + 32];
+
+    const uint8_t *raw = P.raw;
+    uint8_t *out = P.ust + sg.out_off;
+    const uint64_t a0 = sg.raw_begin & ~15ull;
+    uint32_t rem = 0, outpos = 0, carry = 0;
+
+    auto load_tile = [&](uint64_t a) -> uint4 {
+        uint64_t my = a + (uint64_t)lane * 16u;
+        if (my < sg.raw_end) return *reinterpret_cast<const uint4 *>(raw + my);
+        return make_uint4(0, 0, 0, 0);
+    };
+
+    uint4 cur = load_tile(a0);
+    for (uint64_t a = a0; a < sg.raw_end; a += 1024u) {
+        uint4 nxt = load_tile(a + 1024u);
+        const uint64_t my = a + (uint64_t)lane * 16u;
+        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+        // is the last byte of this lane an in-range FF?  (needed by the next lane / next tile)
+        uint32_t lastff = ((w[3] >> 24) == 0xFFu) && (my + 15u >= sg.raw_begin) && (my + 15u < sg.raw_end);
+        uint32_t prevff = __shfl_up(lastff, 1, 64);
+        if (lane == 0) prevff = carry;
+        carry = __shfl(lastff, 63, 64);
+
+        uint32_t keep = 0, pf = prevff;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            uint32_t byte = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            uint64_t pos = my + (uint64_t)k;
+            bool inr = pos >= sg.raw_begin && pos < sg.raw_end;
+            bool drop = (byte == 0u) && pf;
+            if (inr && !drop) keep |= 1u << k;
+            pf = inr && (byte == 0xFFu);
+        }
+        uint32_t n = __popc(keep);
+        uint32_t inc = wave_incl_scan(n, lane);
+        uint32_t total = __shfl(inc, 63, 64);
+        uint32_t o = rem + inc - n;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (keep & (1u << k)) buf[o++] = (uint8_t)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+        }
+        __syncthreads();
+        const uint32_t have = rem + total;
+        const uint32_t full = have & ~15u;
+        if (lane * 16u < full) {
+            uint4 v = *reinterpret_cast<const uint4 *>(buf + lane * 16u);
+            *reinterpret_cast<uint4 *>(out + outpos + lane * 16u) = v;
+        }
+        uint8_t tmp = 0;
+        const uint32_t left = have - full;
+        if (full > 0 && lane < left) tmp = buf[full + lane];
+        __syncthreads();
+        if (full > 0 && lane < left) buf[lane] = tmp;
+        __syncthreads();
+        rem = left;
+        outpos += full;
+        cur = nxt;
+    }
+    // tail: the last partial piece, then zeros up to the end of the slot
+    if (lane >= rem && lane < 16u) buf[lane] = 0;
+    __syncthreads();
+    for (uint32_t off = outpos + lane * 16u; off < sg.out_cap; off += 1024u) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (off == outpos && rem > 0) v = *reinterpret_cast<const uint4 *>(buf);
+        *reinterpret_cast<uint4 *>(out + off) = v;
+    }
+    if (lane == 0) P.seg_payload_bits[s] = (outpos + rem) * 8u;
+}
+
+// ---------------------------------------------------------------------------------- k1a: sync
+// 256 threads = 4 wavefronts = 4 chunks of 64 subsequences, all of one image (table set in LDS).
+__global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
+    __shared__ uint32_t sinfo_lds[4][64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t chunk = blockIdx.x * 4u + wave;
+    const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
+    const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
+    load_lut_to_lds(lut, P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
+    const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
+    ZjSel sel = {im.bpm, im.dcsel, im.acsel};
+    __syncthreads();
+
+    const uint32_t seg = P.chunk_seg[chunk];
+    volatile uint32_t *si = sinfo_lds[wave];
+    uint32_t info = 0;
+    bool done = true;
+    ZjSegDev sg = {};
+    uint32_t jl = 0, pay = 0;
+    const uint32_t SB = P.subbits;
+    const uint32_t *stream = nullptr;
+    ZjState st = {0, 0, 0};
+    if (seg != ZJ_NONE) {
+        sg = P.segs[seg];
+        jl = chunk * 64u + lane - sg.first_sub;
+        pay = P.seg_payload_bits[seg];
+        stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
+        if (sub_active(sg, jl, SB, pay)) {
+            done = false;
+            st.p = jl * SB;
+            uint32_t n = zj_decode_span<false>(stream, lut, canon, sel, st, sub_end(jl, SB, pay), nullptr);
+            info = zj_pack_info(st, (jl + 1u) * SB, n);
+        }
+    }
+    si[lane] = info;
+    // rounds: lane i walks subsequence i+k from the state it carries
+    for (uint32_t k = 1; k < 64u; k++) {
+        const uint32_t tgt = lane + k;
+        const bool act = !done && tgt < 64u && sub_active(sg, jl + k, SB, pay);
+        if (!act) done = true;
+        if (!__any(act)) break;
+        if (act) {
+            uint32_t n = zj_decode_span<false>(stream, lut, canon, sel, st, sub_end(jl + k, SB, pay), nullptr);
+            uint32_t nw = zj_pack_info(st, (jl + k + 1u) * SB, n);
+            uint32_t old = si[tgt];
+            si[tgt] = nw;
+            if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0u) done = true;
+        }
+    }
+    P.sinfo[(size_t)chunk * 64u + lane] = si[lane];
+}
+
+// ---------------------------------------------------------------------------------- k1b: fix
+// One lane per chunk: starts from the state recorded at the end of the previous chunk and rewrites
+// the records of its own chunk until it meets a record that already agrees.
+__global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
+{
+    const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+    if (c >= P.nchunks) return;
+    const uint32_t seg = P.chunk_seg[c];
+    if (seg == ZJ_NONE) return;
+    const ZjSegDev sg = P.segs[seg];
+    if (c * 64u == sg.first_sub) return; // the first chunk of a segment starts from the true state
+    const uint32_t SB = P.subbits;
+    const uint32_t pay = P.seg_payload_bits[seg];
+    const uint32_t jl0 = c * 64u - sg.first_sub;
+    if (!sub_active(sg, jl0, SB, pay)) return;
+    const ZjImgDev &im = P.imgs[sg.img];
+    const uint16_t *lut = P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES;
+    const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
+    ZjSel sel = {im.bpm, im.dcsel, im.acsel};
+    const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
+    ZjState st = zj_unpack_state(P.sinfo[(size_t)c * 64u - 1u], jl0 * SB);
+    for (uint32_t t = 0; t < 64u; t++) {
+        const uint32_t q = jl0 + t;
+        if (!sub_active(sg, q, SB, pay)) break;
+        uint32_t n = zj_decode_span<false>(stream, lut, canon, sel, st, sub_end(q, SB, pay), nullptr);
+        uint32_t nw = zj_pack_info(st, (q + 1u) * SB, n);
+        uint32_t old = P.sinfo[(size_t)c * 64u + t];
+        P.sinfo[(size_t)c * 64u + t] = nw;
+        if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0u) break;
+        if (t == 63u) atomicOr(&P.flags[0], 1u); // ran through the whole chunk: the next one may be stale
+    }
+}
+
+// ---------------------------------------------------------------------------------- k1s: scan
+// One workgroup per segment: base[j] = number of blocks that begin before subsequence j.
+__global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
+{
+    __shared__ uint32_t wsum[8];
+    const uint32_t s = blockIdx.x;
+    const ZjSegDev sg = P.segs[s];
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < sg.nsub; t0 += 256u) {
+        const uint32_t q = t0 + threadIdx.x;
+        uint32_t n = q < sg.nsub ? (P.sinfo[(size_t)sg.first_sub + q] >> 16) : 0u;
+        uint32_t total;
+        uint32_t inc = block_incl_scan<4>(n, wsum, &total);
+        if (q < sg.nsub) P.base[(size_t)sg.first_sub + q] = carry + inc - n;
+        carry += total;
+    }
+    if (threadIdx.x == 0) P.seg_found[s] = carry;
+}
+
+// ---------------------------------------------------------------------------------- k1i: index
+__global__ __launch_bounds__(256) void zj_k1i_index(ZjParams P)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t chunk = blockIdx.x * 4u + wave;
+    const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
+    const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
+    load_lut_to_lds(lut, P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
+    const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
+    ZjSel sel = {im.bpm, im.dcsel, im.acsel};
+    __syncthreads();
+    const uint32_t seg = P.chunk_seg[chunk];
+    if (seg == ZJ_NONE) return;
+    const ZjSegDev sg = P.segs[seg];
+    const uint32_t SB = P.subbits;
+    const uint32_t pay = P.seg_payload_bits[seg];
+    const size_t j = (size_t)chunk * 64u + lane;
+    const uint32_t jl = (uint32_t)(j - sg.first_sub);
+    if (!sub_active(sg, jl, SB, pay)) return;
+    const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
+    ZjState st = {0, 0, 0};
+    if (jl > 0) st = zj_unpack_state(P.sinfo[j - 1u], jl * SB);
+    ZjIndexOut io = {P.blockpos + sg.first_block, P.dcdiff + sg.first_block, P.base[j], sg.nblocks};
+    uint32_t n = zj_decode_span<true>(stream, lut, canon, sel, st, sub_end(jl, SB, pay), &io);
+    uint32_t nw = zj_pack_info(st, (jl + 1u) * SB, n);
+    if (nw != P.sinfo[j]) atomicOr(&P.flags[1], 1u); // the chain of records is not consistent yet
+}
+
+// ---------------------------------------------------------------------------------- k1d: DC scan
+// One workgroup per segment, one lane per MCU per step.  dc[g] = sum of the DC differences of the
+// same component up to and including block g, i16 wrapping (src/decoder.rs:199-200; the predictors
+// start at 0 in every segment, :376).
+__global__ __launch_bounds__(256) void zj_k1d_dcscan(ZjParams P)
+{
+    __shared__ uint32_t wsum[8];
+    const uint32_t s = blockIdx.x;
+    const ZjSegDev sg = P.segs[s];
+    const ZjImgDev &im = P.imgs[sg.img];
+    const uint32_t bpm = im.bpm, compsel = im.compsel;
+    const uint32_t found = min(P.seg_found[s], sg.nblocks);
+    const uint32_t nmcu = sg.nblocks / bpm;
+    const int16_t *dd = P.dcdiff + sg.first_block;
+    int16_t *da = P.dcabs + sg.first_block;
+    uint32_t carry[3] = {0, 0, 0};
+    for (uint32_t m0 = 0; m0 < nmcu; m0 += 256u) {
+        const uint32_t m = m0 + threadIdx.x;
+        uint32_t d[6] = {0, 0, 0, 0, 0, 0}, loc[3] = {0, 0, 0};
+#pragma unroll
+        for (uint32_t k = 0; k < 6u; k++) {
+            uint32_t g = m * bpm + k;
+            if (k < bpm && m < nmcu && g < found) d[k] = (uint32_t)(int32_t)dd[g];
+            uint32_t c = (compsel >> (2u * k)) & 3u;
+#pragma unroll
+            for (uint32_t cc = 0; cc < 3u; cc++)
+                if (c == cc && k < bpm) loc[cc] += d[k];
+        }
+        uint32_t run[3];
+#pragma unroll
+        for (uint32_t cc = 0; cc < 3u; cc++) {
+            uint32_t total;
+            uint32_t inc = block_incl_scan<4>(loc[cc], wsum, &total);
+            run[cc] = carry[cc] + inc - loc[cc];
+            carry[cc] += total;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 6u; k++) {
+            uint32_t g = m * bpm + k;
+            uint32_t c = (compsel >> (2u * k)) & 3u;
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t cc = 0; cc < 3u; cc++)
+                if (c == cc && k < bpm) { run[cc] += d[k]; v = run[cc]; }
+            if (k < bpm && m < nmcu) da[g] = (int16_t)v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- k1w: write
+// 256 threads = 256 consecutive blocks of one image.  Each lane decodes its block into a private
+// 132-byte row of an LDS tile (row stride of 33 words keeps lanes on distinct banks while they
+// write the same zig-zag index), then the wavefront stores its 64 rows as 8 KiB of contiguous,
+// fully coalesced 16-byte pieces.
+__global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
+    __shared__ uint32_t tile[4][64 * 33];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t g0 = blockIdx.x * 256u;
+    const uint32_t ii = P.blk256_img[blockIdx.x];
+    const ZjImgDev &im = P.imgs[ii];
+    load_lut_to_lds(lut, P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
+    const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
+    uint32_t *row32 = &tile[wave][lane * 33u];
+#pragma unroll
+    for (int i = 0; i < 33; i++) row32[i] = 0;
+    __syncthreads();
+
+    const uint32_t g = g0 + threadIdx.x;
+    const uint32_t gl = g - im.first_block;
+    if (gl < im.nblocks) {
+        const uint32_t segi = im.ri_blocks ? gl / im.ri_blocks : 0u;
+        const uint32_t seg = im.first_seg + segi;
+        const uint32_t gs = gl - segi * im.ri_blocks;
+        const uint64_t out_off = P.segs[seg].out_off;
+        const uint32_t found = P.seg_found[seg];
+        uint32_t st;
+        if (gs < found) {
+            const uint32_t k = gs % im.bpm;
+            const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + out_off);
+            uint32_t pend;
+            st = zj_decode_block(stream, lut, canon, (im.dcsel >> k) & 1u, (im.acsel >> k) & 1u, P.blockpos[g],
+                                 P.dcabs[g], reinterpret_cast<int16_t *>(row32), &pend);
+            if (pend > P.seg_payload_bits[seg]) st |= 4u; // ZJ_ST_TRUNCATED
+        } else {
+            st = 4u;
+        }
+        if (st) atomicOr(&P.status[ii], st);
+    }
+    __syncthreads();
+    int16_t *dst = P.qcoef + ((size_t)g0 + wave * 64u) * 64u;
+#pragma unroll
+    for (uint32_t it = 0; it < 8u; it++) {
+        const uint32_t q = it * 64u + lane;
+        const uint32_t blk = q >> 3, part = q & 7u;
+        const uint32_t *src = &tile[wave][blk * 33u + part * 4u];
+        uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
+        *reinterpret_cast<uint4 *>(dst + (size_t)q * 8u) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------- k2: IDCT + colour
+// COS_TABLE of src/dct.rs:19-84 by bit pattern: c[m] = cos(m*pi/16) rounded to f32, m = 1..7.
+#define ZJ_C1 0x3f7b14beu
+#define ZJ_C2 0x3f6c835eu
+#define ZJ_C3 0x3f54db31u
+#define ZJ_C4 0x3f3504f3u
+#define ZJ_C5 0x3f0e39dau
+#define ZJ_C6 0x3ec3ef15u
+#define ZJ_C7 0x3e47c5c2u
+
+__device__ __forceinline__ constexpr uint32_t zj_cos_bits(int n, int k)
+{
+    if (k == 0) return ZJ_C4;
+    int m = ((2 * n + 1) * k) & 31;
+    bool neg = false;
+    if (m > 16) m = 32 - m;
+    if (m > 8) { m = 16 - m; neg = true; }
+    uint32_t mag = m == 1 ? ZJ_C1 : m == 2 ? ZJ_C2 : m == 3 ? ZJ_C3 : m == 4 ? ZJ_C4 : m == 5 ? ZJ_C5 : m == 6 ? ZJ_C6 : ZJ_C7;
+    return neg ? (mag | 0x80000000u) : mag;
+}
+
+// src/dct.rs:87-99: out[n] = 0.5 * fma(in7, C[n][7], ... fma(in0, C[n][0], 0.0)), ascending k.
+__device__ __forceinline__ void zj_idct_1d(const float (&in)[8], float (&out)[8])
+{
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s = __builtin_fmaf(in[k], __uint_as_float(zj_cos_bits(n, k)), s);
+        out[n] = s * 0.5f;
+    }
+}
+
+// Rust `as u8` (src/decoder.rs:275-277): truncate toward zero, saturate, NaN -> 0.
+__device__ __forceinline__ uint32_t zj_f32_as_u8(float v)
+{
+    v = fmaxf(v, 0.0f); // NaN -> 0
+    v = fminf(v, 255.0f);
+    return (uint32_t)(int)v;
+}
+
+// Natural index of the zig-zag positions 8*part .. 8*part+7, six bits each (inverse of the table at
+// src/decoder.rs:114-124).
+__constant__ uint64_t zj_zz2nat_packed[8] = {
+    // filled from the walk below at load time would need host code; the values are the zig-zag scan
+    // order of T.81 Figure A.6 grouped by eight.
+    (0ull) | (1ull << 6) | (8ull << 12) | (16ull << 18) | (9ull << 24) | (2ull << 30) | (3ull << 36) | (10ull << 42),
+    (17ull) | (24ull << 6) | (32ull << 12) | (25ull << 18) | (18ull << 24) | (11ull << 30) | (4ull << 36) | (5ull << 42),
+    (12ull) | (19ull << 6) | (26ull << 12) | (33ull << 18) | (40ull << 24) | (48ull << 30) | (41ull << 36) | (34ull << 42),
+    (27ull) | (20ull << 6) | (13ull << 12) | (6ull << 18) | (7ull << 24) | (14ull << 30) | (21ull << 36) | (28ull << 42),
+    (35ull) | (42ull << 6) | (49ull << 12) | (56ull << 18) | (57ull << 24) | (50ull << 30) | (43ull << 36) | (36ull << 42),
+    (29ull) | (22ull << 6) | (15ull << 12) | (23ull << 18) | (30ull << 24) | (37ull << 30) | (44ull << 36) | (51ull << 42),
+    (58ull) | (59ull << 6) | (52ull << 12) | (45ull << 18) | (38ull << 24) | (31ull << 30) | (39ull << 36) | (46ull << 42),
+    (53ull) | (60ull << 6) | (61ull << 12) | (54ull << 18) | (47ull << 24) | (55ull << 30) | (62ull << 36) | (63ull << 42),
+};
+
+#define ZJ_K2_BLOCKS 96
+#define ZJ_K2_BSTRIDE 72 // floats per block in LDS: 64 + 8 keeps the column pass conflict-free
+
+template <int HS, int VS>
+__device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im, uint32_t ii, uint32_t strip,
+                                           float *blk)
+{
+    constexpr int BPM = HS * VS + 2;
+    constexpr int T = ZJ_K2_BLOCKS / BPM; // MCUs per strip
+    constexpr int MW = 8 * HS, MH = 8 * VS;
+    constexpr int ROWB = T * MW * 3;      // bytes of one pixel row of the strip
+    const uint32_t tid = threadIdx.x;
+    const uint32_t my = strip / im.strips_x, sx = strip % im.strips_x;
+    const uint32_t x0 = sx * T;
+    const uint32_t nm = min((uint32_t)T, im.mcux - x0);
+    const uint32_t nb = nm * BPM;
+    const int16_t *src = P.qcoef + ((size_t)im.first_block + ((size_t)my * im.mcux + x0) * BPM) * 64u;
+
+    // phase 1: coalesced 16-byte loads, dequantise (i16 wrapping, both operands in zig-zag order,
+    // src/decoder.rs:179-184), de-zigzag into LDS as f32 (exact), src/decoder.rs:296-300
+#pragma unroll
+    for (uint32_t i = 0; i < 3u; i++) {
+        const uint32_t q = tid + i * 256u;
+        const uint32_t b = q >> 3, part = q & 7u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (b < nb) v = *reinterpret_cast<const uint4 *>(src + (size_t)q * 8u);
+        const uint32_t kb = b % BPM;
+        const uint32_t comp = kb < (uint32_t)(HS * VS) ? 0u : (kb == (uint32_t)(HS * VS) ? 1u : 2u);
+        const uint2 qq = *reinterpret_cast<const uint2 *>(P.qts + im.qt_off[comp] + part * 8u);
+        const uint64_t nat = zj_zz2nat_packed[part];
+        const uint32_t cw[4] = {v.x, v.y, v.z, v.w};
+        float *bp = blk + b * ZJ_K2_BSTRIDE;
+#pragma unroll
+        for (uint32_t e = 0; e < 8u; e++) {
+            int32_t c = (int16_t)(cw[e >> 1] >> (16u * (e & 1u)));
+            uint32_t qv = ((e < 4u ? qq.x : qq.y) >> (8u * (e & 3u))) & 0xFFu;
+            int16_t dq = (int16_t)(c * (int32_t)qv);
+            bp[(uint32_t)(nat >> (6u * e)) & 63u] = (float)dq;
+        }
+    }
+    __syncthreads();
+    // phase 2: 1-D IDCT over the columns of every block, in place (src/dct.rs:104-111)
+#pragma unroll
+    for (uint32_t i = 0; i < 3u; i++) {
+        const uint32_t q = tid + i * 256u;
+        const uint32_t b = q >> 3, col = q & 7u;
+        float *bp = blk + b * ZJ_K2_BSTRIDE + col;
+        float in[8], out[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) in[k] = bp[k * 8];
+        zj_idct_1d(in, out);
+#pragma unroll
+        for (int n = 0; n < 8; n++) bp[n * 8] = out[n];
+    }
+    __syncthreads();
+    // phase 3: 1-D IDCT over the rows (src/dct.rs:113-120), +128, replicate chroma, colour
+    // (src/decoder.rs:306-312).  One lane per (pixel row r, MCU m) of the strip.
+    constexpr int NTASK = T * MH;
+    constexpr int NIT = (NTASK + 255) / 256;
+    uint32_t px[NIT][MW * 3 / 4];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const uint32_t q = tid + it * 256u;
+        const uint32_t m = q / MH, r = q % MH;
+        uint8_t bytes[MW * 3];
+        if (q < (uint32_t)NTASK) {
+            float cb[8], cr[8], in[8];
+            const float *cbp = blk + (m * BPM + HS * VS) * ZJ_K2_BSTRIDE + (r / VS) * 8u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) in[k] = cbp[k];
+            zj_idct_1d(in, cb);
+#pragma unroll
+            for (int k = 0; k < 8; k++) in[k] = cbp[ZJ_K2_BSTRIDE + k];
+            zj_idct_1d(in, cr);
+#pragma unroll
+            for (int u = 0; u < HS; u++) {
+                float yv[8];
+                const float *yp = blk + (m * BPM + (r / 8u) * HS + u) * ZJ_K2_BSTRIDE + (r % 8u) * 8u;
+#pragma unroll
+                for (int k = 0; k < 8; k++) in[k] = yp[k];
+                zj_idct_1d(in, yv);
+#pragma unroll
+                for (int x = 0; x < 8; x++) {
+                    const int cx = (u * 8 + x) / HS;
+                    const float y = yv[x] + 128.0f;
+                    const float cbv = cb[cx] + 128.0f;
+                    const float crv = cr[cx] + 128.0f;
+                    // src/decoder.rs:271-273: separate multiplies and adds, left to right
+                    const float rr = 1.402f * (crv - 128.0f) + y;
+                    const float gg = -0.71414f * (crv - 128.0f) + -0.34414f * (cbv - 128.0f) + y;
+                    const float bb = 1.772f * (cbv - 128.0f) + y;
+                    bytes[(u * 8 + x) * 3 + 0] = (uint8_t)zj_f32_as_u8(rr);
+                    bytes[(u * 8 + x) * 3 + 1] = (uint8_t)zj_f32_as_u8(gg);
+                    bytes[(u * 8 + x) * 3 + 2] = (uint8_t)zj_f32_as_u8(bb);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MW * 3; i++) bytes[i] = 0;
+        }
+#pragma unroll
+        for (int w4 = 0; w4 < MW * 3 / 4; w4++)
+            px[it][w4] = (uint32_t)bytes[4 * w4] | ((uint32_t)bytes[4 * w4 + 1] << 8) | ((uint32_t)bytes[4 * w4 + 2] << 16) |
+                         ((uint32_t)bytes[4 * w4 + 3] << 24);
+    }
+    __syncthreads();
+    // phase 4: RGB rows of the strip into LDS (reusing the block area), then one linear, coalesced
+    // copy per pixel row (src/decoder.rs:314-315 writes the same bytes pixel by pixel)
+    uint32_t *stage = reinterpret_cast<uint32_t *>(blk);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const uint32_t q = tid + it * 256u;
+        const uint32_t m = q / MH, r = q % MH;
+        if (q < (uint32_t)NTASK) {
+            uint32_t *d = stage + (r * ROWB + m * MW * 3) / 4;
+#pragma unroll
+            for (int w4 = 0; w4 < MW * 3 / 4; w4++) d[w4] = px[it][w4];
+        }
+    }
+    __syncthreads();
+    uint8_t *rgb = P.rgb[ii];
+    if (rgb == nullptr) return;
+    const size_t stride = P.rgb_stride[ii] ? P.rgb_stride[ii] : (size_t)im.w * 3u;
+    const uint32_t row_valid = min((uint32_t)ROWB, (im.w - min(im.w, x0 * MW)) * 3u); // bytes inside the image
+    const uint32_t rows_valid = min((uint32_t)MH, im.h - min(im.h, my * MH));
+    const bool vec_ok = (((uintptr_t)rgb | stride) & 15u) == 0;
+    constexpr int PIECES = ROWB / 16;
+    for (uint32_t q = tid; q < (uint32_t)(PIECES * MH); q += 256u) {
+        const uint32_t r = q / PIECES, pc = q % PIECES;
+        if (r >= rows_valid) continue;
+        const uint32_t off = pc * 16u;
+        if (off >= row_valid) continue;
+        uint8_t *dst = rgb + (size_t)(my * MH + r) * stride + (size_t)x0 * MW * 3u + off;
+        const uint32_t *s4 = stage + (r * ROWB + off) / 4;
+        if (vec_ok && off + 16u <= row_valid) {
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(s4[0], s4[1], s4[2], s4[3]);
+        } else {
+            const uint32_t nbytes = min(16u, row_valid - off);
+            for (uint32_t i = 0; i < nbytes; i++) dst[i] = (uint8_t)(s4[i >> 2] >> (8u * (i & 3u)));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void zj_k2_idct_rgb(ZjParams P)
+{
+    __shared__ __attribute__((aligned(16))) float blk[ZJ_K2_BLOCKS * ZJ_K2_BSTRIDE];
+    const uint32_t ii = P.strip_img[blockIdx.x];
+    const ZjImgDev &im = P.imgs[ii];
+    const uint32_t strip = blockIdx.x - im.first_strip;
+    if (im.hs == 2 && im.vs == 2) zj_k2_body<2, 2>(P, im, ii, strip, blk);
+    else if (im.hs == 1 && im.vs == 1) zj_k2_body<1, 1>(P, im, ii, strip, blk);
+    else if (im.hs == 2 && im.vs == 1) zj_k2_body<2, 1>(P, im, ii, strip, blk);
+    else zj_k2_body<1, 2>(P, im, ii, strip, blk);
+}
+
+// ---------------------------------------------------------------------------------- export (tests)
+// dqcoef[b][nat] = qcoef[b][zz] * q[zz]: the reference's `blocks` entry (src/decoder.rs:237-240).
+__global__ __launch_bounds__(256) void zj_kx_dequant(ZjParams P, uint32_t ii, int16_t *dst)
+{
+    const ZjImgDev &im = P.imgs[ii];
+    const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (idx >= (size_t)im.nblocks * 64u) return;
+    const uint32_t b = (uint32_t)(idx >> 6), zz = (uint32_t)(idx & 63u);
+    const uint32_t kb = b % im.bpm;
+    const uint32_t comp = (im.compsel >> (2u * kb)) & 3u;
+    const int32_t c = P.qcoef[(size_t)im.first_block * 64u + idx];
+    const int32_t qv = P.qts[im.qt_off[comp] + zz];
+    const uint32_t nat = (uint32_t)(zj_zz2nat_packed[zz >> 3] >> (6u * (zz & 7u))) & 63u;
+    dst[(size_t)b * 64u + nat] = (int16_t)(c * qv);
+}
+
+// ---------------------------------------------------------------------------------- launchers
+extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream_t st, hipEvent_t *ev)
+{
+    int e = 0;
+    if (ev) hipEventRecord(ev[e++], st);
+    hipMemsetAsync(P.flags, 0, 16, st);
+    hipLaunchKernelGGL(zj_k0_unstuff, dim3(L.nseg), dim3(64), 0, st, P);
+    if (ev) hipEventRecord(ev[e++], st);
+    hipLaunchKernelGGL(zj_k1a_sync, dim3(L.nchunks / 4), dim3(256), 0, st, P);
+    if (ev) hipEventRecord(ev[e++], st);
+    for (int i = 0; i < L.fix_iters; i++) hipLaunchKernelGGL(zj_k1b_fix, dim3((L.nchunks + 63) / 64), dim3(64), 0, st, P);
+    if (ev) hipEventRecord(ev[e++], st);
+    hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
+    if (ev) hipEventRecord(ev[e++], st);
+    hipLaunchKernelGGL(zj_k1i_index, dim3(L.nchunks / 4), dim3(256), 0, st, P);
+    if (ev) hipEventRecord(ev[e++], st);
+    hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.nseg), dim3(256), 0, st, P);
+    if (ev) hipEventRecord(ev[e++], st);
+    hipLaunchKernelGGL(zj_k1w_write, dim3(L.nblk256), dim3(256), 0, st, P);
+    if (ev) hipEventRecord(ev[e++], st);
+}
+
+extern "C" void zj_launch_fix_only(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
+{
+    hipLaunchKernelGGL(zj_k1b_fix, dim3((L.nchunks + 63) / 64), dim3(64), 0, st, P);
+}
+
+extern "C" void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
+{
+    hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(zj_k1i_index, dim3(L.nchunks / 4), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.nseg), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(zj_k1w_write, dim3(L.nblk256), dim3(256), 0, st, P);
+}
+
+extern "C" void zj_launch_stage2(const ZjParams &P, const ZjLaunch &L, hipStream_t st, hipEvent_t *ev)
+{
+    if (L.nstrips) hipLaunchKernelGGL(zj_k2_idct_rgb, dim3(L.nstrips), dim3(256), 0, st, P);
+    if (ev) hipEventRecord(ev[0], st);
+}
+
+extern "C" void zj_launch_dequant(const ZjParams &P, uint32_t ii, uint32_t nblocks, int16_t *dst, hipStream_t st)
+{
+    uint32_t n = (uint32_t)(((size_t)nblocks * 64u + 255u) / 256u);
+    if (n) hipLaunchKernelGGL(zj_kx_dequant, dim3(n), dim3(256), 0, st, P, ii, dst);
+}

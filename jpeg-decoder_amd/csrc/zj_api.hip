@@ -237,7 +237,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             s.raw_end = raw_off[i] + end;
             const size_t rl = end - beg;
             s.out_off = ust_total;
-            s.out_cap = (uint32_t)(align_up(rl, 16) + 16);
+            s.out_cap = (uint32_t)(align_up(rl, 16) + 96);
             ust_total += s.out_cap;
             s.img = (uint32_t)i;
             s.nsub = (uint32_t)((rl * 8 + subbits - 1) / subbits);

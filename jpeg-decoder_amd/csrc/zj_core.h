@@ -13,9 +13,11 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#define ZJ_HD_NOINLINE __attribute__((host)) __attribute__((device)) inline __attribute__((noinline))
 #define ZJ_HD __attribute__((host)) __attribute__((device)) inline __attribute__((always_inline))
 #else
 #define ZJ_HD inline
+#define ZJ_HD_NOINLINE inline
 #endif
 
 // ---- lookup-table format -------------------------------------------------------------------
@@ -112,22 +114,48 @@ ZJ_HD uint32_t zj_bswap32(uint32_t x)
 #endif
 }
 
-// MSB-first reader.  `base` is the 4-byte aligned start of a segment's unstuffed stream; the arena
-// keeps at least 16 readable, zero-filled bytes behind every segment, which reproduces the
-// reference's zero padding at the end of data (src/bitstream.rs:80-84).
+// MSB-first reader.  `base` is the 16-byte aligned start of a segment's unstuffed stream; the arena
+// keeps readable, zero-filled bytes behind every segment, which reproduces the reference's zero
+// padding at the end of data (src/bitstream.rs:80-84).  The stream is fetched in 16-byte pieces, one
+// piece ahead of the one being consumed, so that the load of piece n+1 is in flight while the ~24
+// symbols of piece n are decoded (a lane's loads are far apart in memory from its neighbours'; what
+// hides their latency is this distance between issue and use, not coalescing).
+struct alignas(16) ZjU4 {
+    uint32_t x, y, z, w;
+};
+
 struct ZjBits {
-    const uint32_t *base;
-    uint32_t widx; // next word to load
+    const ZjU4 *base;
+    uint32_t pidx; // next piece to load
+    ZjU4 cur, nxt; // piece being consumed (shifted down as words leave), piece after it
+    uint32_t left; // words left in cur
     uint64_t buf;  // left-aligned window
     int32_t cnt;   // valid bits in buf, always > 32 between calls
 
+    ZJ_HD uint32_t take()
+    {
+        if (left == 0) {
+            cur = nxt;
+            left = 4;
+            nxt = base[pidx++];
+        }
+        uint32_t w = cur.x;
+        cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
+        left--;
+        return zj_bswap32(w);
+    }
     ZJ_HD void init(const uint32_t *b, uint32_t bitpos)
     {
-        base = b;
-        widx = bitpos >> 5;
-        uint64_t w0 = zj_bswap32(base[widx]), w1 = zj_bswap32(base[widx + 1]);
-        widx += 2;
-        uint32_t sh = bitpos & 31u;
+        base = reinterpret_cast<const ZjU4 *>(b);
+        const uint32_t word = bitpos >> 5, piece = word >> 2;
+        cur = base[piece];
+        nxt = base[piece + 1];
+        pidx = piece + 2;
+        left = 4;
+        if (word & 1u) { cur.x = cur.y; cur.y = cur.z; cur.z = cur.w; left -= 1; }
+        if (word & 2u) { cur.x = cur.z; cur.y = cur.w; left -= 2; }
+        uint64_t w0 = take(), w1 = take();
+        const uint32_t sh = bitpos & 31u;
         buf = ((w0 << 32) | w1) << sh;
         cnt = 64 - (int32_t)sh;
     }
@@ -137,7 +165,68 @@ struct ZjBits {
         buf <<= n;
         cnt -= (int32_t)n;
         if (cnt <= 32) {
-            uint64_t w = zj_bswap32(base[widx++]);
+            uint64_t w = take();
+            buf |= w << (32 - cnt);
+            cnt += 32;
+        }
+    }
+};
+
+// Reader for one block (the per-block write pass): 64 bytes are fetched up front, which covers a
+// block of at least 385 bits without another load inside the symbol loop; longer blocks reload.
+struct ZjBits4 {
+    const ZjU4 *base;
+    uint32_t widx; // stream word index of the next word to take
+    ZjU4 cur, n1, n2, n3;
+    uint32_t left; // words left in cur..n3
+    uint64_t buf;
+    int32_t cnt;
+
+    ZJ_HD void fill(uint32_t word)
+    {
+        const uint32_t piece = word >> 2;
+        cur = base[piece]; n1 = base[piece + 1]; n2 = base[piece + 2]; n3 = base[piece + 3];
+        left = 16;
+        if (word & 1u) { cur.x = cur.y; cur.y = cur.z; cur.z = cur.w; left -= 1; }
+        if (word & 2u) { cur.x = cur.z; cur.y = cur.w; left -= 2; }
+        widx = word;
+    }
+    ZJ_HD uint32_t take()
+    {
+        if (left == 0) fill(widx);
+        else if ((left & 3u) == 0) { cur = n1; n1 = n2; n2 = n3; }
+        uint32_t w = cur.x;
+        cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
+        left--;
+        widx++;
+        return zj_bswap32(w);
+    }
+    ZJ_HD void init(const uint32_t *b, uint32_t bitpos)
+    {
+        base = reinterpret_cast<const ZjU4 *>(b);
+        fill(bitpos >> 5);
+        // fill() leaves `left` one short of a multiple of four exactly when words were skipped, so the
+        // piece rotation in take() must not fire before the first piece is used up
+        uint64_t w0 = take_first(), w1 = take();
+        const uint32_t sh = bitpos & 31u;
+        buf = ((w0 << 32) | w1) << sh;
+        cnt = 64 - (int32_t)sh;
+    }
+    ZJ_HD uint32_t take_first()
+    {
+        uint32_t w = cur.x;
+        cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
+        left--;
+        widx++;
+        return zj_bswap32(w);
+    }
+    ZJ_HD uint32_t top32() const { return (uint32_t)(buf >> 32); }
+    ZJ_HD void skip(uint32_t n)
+    {
+        buf <<= n;
+        cnt -= (int32_t)n;
+        if (cnt <= 32) {
+            uint64_t w = take();
             buf |= w << (32 - cnt);
             cnt += 32;
         }
@@ -147,7 +236,7 @@ struct ZjBits {
 // ---- one Huffman symbol ----------------------------------------------------------------------
 // Canonical search, the textbook form of src/ec.rs:30-47 (first length whose code range holds the
 // window).  Returns an entry in the short format, 0 if the window starts no code.
-ZJ_HD uint32_t zj_canon_lookup(const ZjCanon *c, uint32_t top32)
+ZJ_HD_NOINLINE uint32_t zj_canon_lookup(const ZjCanon *c, uint32_t top32)
 {
     uint32_t w16 = top32 >> 16;
     for (uint32_t l = 1; l <= 16; l++) {
@@ -184,6 +273,18 @@ struct ZjSel { // table selectors of the image a lane works on
     uint32_t bpm, dcsel, acsel;
 };
 
+// Table index (0 = DC id 0, 1 = DC id 1, 2 = AC id 0, 3 = AC id 1) of block k of the MCU as one word:
+// bits [2k+1:2k] for the block's DC symbol, bits [2k+17:2k+16] for its AC symbols.
+ZJ_HD uint32_t zj_selword(const ZjSel &s)
+{
+    uint32_t w = 0;
+    for (uint32_t k = 0; k < 8u; k++) {
+        w |= ((s.dcsel >> k) & 1u) << (2u * k);
+        w |= (2u + ((s.acsel >> k) & 1u)) << (2u * k + 16u);
+    }
+    return w;
+}
+
 // What a span decode records besides the state.
 struct ZjIndexOut {
     uint32_t *blockpos; // [segment block] bit position of the block's DC symbol
@@ -195,49 +296,58 @@ struct ZjIndexOut {
 // Walk the symbols that START inside [st.p, end) -- the serial loop of src/decoder.rs:194-235 seen
 // as a state machine over (bit position, block in MCU, zig-zag index).  Returns the number of
 // blocks that began.  With INDEX it also records where each block begins and its DC difference.
-template <bool INDEX>
-ZJ_HD uint32_t zj_decode_span(const uint32_t *stream, const uint16_t *lut, const ZjCanon *canon, const ZjSel &sel,
-                              ZjState &st, uint32_t end, ZjIndexOut *io)
+// The walk itself, on a reader that is already positioned at st.p: symbols that start before `stop`.
+template <class BITS, bool INDEX>
+ZJ_HD uint32_t zj_decode_run(BITS &bits, const uint16_t *lut, const ZjCanon *canon, uint32_t selw, uint32_t bpm,
+                             ZjState &st, uint32_t stop, ZjIndexOut *io)
 {
     uint32_t nblk = 0;
-    if (st.p >= end) return 0;
-    ZjBits bits;
-    bits.init(stream, st.p);
     uint32_t p = st.p, b = st.b, z = st.z;
-    while (p < end) {
-        uint32_t top = bits.top32();
-        bool isdc = (z == 0);
-        uint32_t t = isdc ? ((sel.dcsel >> b) & 1u) : (2u + ((sel.acsel >> b) & 1u));
-        uint32_t e = zj_lookup(lut + t * ZJ_TBL_ENTRIES, canon ? canon + t : nullptr, top);
-        uint32_t len = (e >> 8) & 31u, sym = e & 255u;
+    while (p < stop) {
+        // everything below is select-based on purpose: lanes of a wavefront sit at different points of
+        // different blocks, so branches on the decoder state would serialise
+        const uint32_t top = bits.top32();
+        const bool isdc = (z == 0);
+        const uint32_t t = (selw >> (2u * b + (isdc ? 0u : 16u))) & 3u;
+        const uint32_t e = zj_lookup(lut + t * ZJ_TBL_ENTRIES, canon ? canon + t : nullptr, top);
+        const uint32_t len = (e >> 8) & 31u, sym = e & 255u;
         uint32_t s = isdc ? sym : (sym & 15u);
-        if (s > 16u) s = 16u;
-        uint32_t tot = len + s;
-        if (len == 0) tot = 1; // no such code: keep moving, the write pass reports it
-        if (isdc) {
-            if (INDEX) {
+        s = s > 16u ? 16u : s;
+        uint32_t tot = len + s; // a DC symbol and its bits, or an AC symbol and its bits: at most 32
+        tot = tot ? tot : 1u;   // no such code: keep moving, the write pass reports it
+        if (INDEX) {
+            if (isdc) {
                 if (io->g < io->glimit) {
-                    uint32_t v = s ? ((top << len) >> (32 - s)) : 0u;
+                    const uint32_t v = s ? ((top << len) >> (32 - s)) : 0u;
                     io->blockpos[io->g] = p;
                     io->dcdiff[io->g] = (int16_t)zj_extend(s, v);
                 }
                 io->g++;
             }
-            nblk++;
-            z = 1;
-        } else if (sym == 0) {
-            z = 0;
-            b++;
-        } else {
-            z += (sym >> 4) + 1u;
-            if (z >= 64u) { z = 0; b++; }
         }
-        if (b >= sel.bpm) b = 0;
+        nblk += isdc ? 1u : 0u;
+        // AC: EOB ends the block, otherwise skip `run` zeros and place one coefficient
+        const uint32_t zac = (sym == 0u) ? 64u : z + (sym >> 4) + 1u;
+        const uint32_t zn = isdc ? 1u : zac;
+        const bool endblk = zn >= 64u;
+        z = endblk ? 0u : zn;
+        b += endblk ? 1u : 0u;
+        b = (b >= bpm) ? 0u : b;
         bits.skip(tot);
         p += tot;
     }
     st.p = p; st.b = b; st.z = z;
     return nblk;
+}
+
+template <bool INDEX>
+ZJ_HD uint32_t zj_decode_span(const uint32_t *stream, const uint16_t *lut, const ZjCanon *canon, const ZjSel &sel,
+                              ZjState &st, uint32_t end, ZjIndexOut *io)
+{
+    if (st.p >= end) return 0;
+    ZjBits bits;
+    bits.init(stream, st.p);
+    return zj_decode_run<ZjBits, INDEX>(bits, lut, canon, zj_selword(sel), sel.bpm, st, end, io);
 }
 
 // Decode one block that begins at bit `p0` into row[0..63] (zig-zag order, already zeroed).
@@ -246,7 +356,7 @@ ZJ_HD uint32_t zj_decode_span(const uint32_t *stream, const uint16_t *lut, const
 ZJ_HD uint32_t zj_decode_block(const uint32_t *stream, const uint16_t *lut, const ZjCanon *canon, uint32_t tdc,
                                uint32_t tac, uint32_t p0, int16_t dc, int16_t *row, uint32_t *pend)
 {
-    ZjBits bits;
+    ZjBits4 bits;
     bits.init(stream, p0);
     uint32_t p = p0, status = 0;
     {

@@ -75,6 +75,86 @@ __device__ __forceinline__ void load_lut_to_lds(uint16_t *lds, const uint16_t *s
     for (uint32_t i = threadIdx.x; i < ZJ_SET_ENTRIES * 2 / 16; i += blockDim.x) d4[i] = s4[i];
 }
 
+// ---------------------------------------------------------------------------------- windowed reader
+// A lane of the subsequence-parallel kernels reads a private, strictly sequential stretch of the
+// stream, far from its neighbours' stretches.  Fetching it word by word from global memory puts a
+// full memory latency into almost every iteration of the symbol loop (one lane or another always
+// needs a word, and the wait counter is per wavefront).  Instead every lane stages 64-byte windows of
+// its own stretch in a private column of LDS -- ZJ_WIN_WORDS words plus two words of look-ahead,
+// word w of lane l at [w][l], so the column reads are bank-conflict free -- with all lanes of the
+// wavefront staging at the same moment, and the symbol loop refills from LDS.
+#define ZJ_WIN_WORDS 16
+#define ZJ_WIN_SLOTS 18
+#define ZJ_WIN_BITS (ZJ_WIN_WORDS * 32)
+
+struct ZjBitsLds {
+    const uint32_t *col; // this lane's column: word slot s at col[s * 64]
+    uint32_t widx;       // next stream word to take
+    uint32_t wbase;      // stream word held in slot 0
+    uint64_t buf;
+    int32_t cnt;
+
+    __device__ __forceinline__ uint32_t take() { return __builtin_bswap32(col[(widx++ - wbase) * 64u]); }
+    __device__ __forceinline__ void init(uint32_t bitpos)
+    {
+        widx = bitpos >> 5;
+        uint64_t w0 = take(), w1 = take();
+        const uint32_t sh = bitpos & 31u;
+        buf = ((w0 << 32) | w1) << sh;
+        cnt = 64 - (int32_t)sh;
+    }
+    __device__ __forceinline__ uint32_t top32() const { return (uint32_t)(buf >> 32); }
+    __device__ __forceinline__ void skip(uint32_t n)
+    {
+        buf <<= n;
+        cnt -= (int32_t)n;
+        if (cnt <= 32) {
+            uint64_t w = take();
+            buf |= w << (32 - cnt);
+            cnt += 32;
+        }
+    }
+};
+
+// Stage the window that holds stream word `w0` (a multiple of ZJ_WIN_WORDS) into this lane's column.
+__device__ __forceinline__ void zj_stage_window(const uint32_t *stream, uint32_t w0, uint32_t *col)
+{
+    const uint4 *src = reinterpret_cast<const uint4 *>(stream + w0);
+    const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+    const uint2 e = *reinterpret_cast<const uint2 *>(stream + w0 + 16);
+    col[0 * 64] = a.x; col[1 * 64] = a.y; col[2 * 64] = a.z; col[3 * 64] = a.w;
+    col[4 * 64] = b.x; col[5 * 64] = b.y; col[6 * 64] = b.z; col[7 * 64] = b.w;
+    col[8 * 64] = c.x; col[9 * 64] = c.y; col[10 * 64] = c.z; col[11 * 64] = c.w;
+    col[12 * 64] = d.x; col[13 * 64] = d.y; col[14 * 64] = d.z; col[15 * 64] = d.w;
+    col[16 * 64] = e.x; col[17 * 64] = e.y;
+}
+
+// zj_decode_span for all lanes of a wavefront at once: lanes with `run` set walk [st.p, end) of their own
+// stream through staged windows.  Must be called by the whole wavefront (it votes).
+template <bool INDEX>
+__device__ __forceinline__ uint32_t zj_span_windowed(bool run, const uint32_t *stream, const uint16_t *lut,
+                                                     const ZjCanon *canon, uint32_t selw, uint32_t bpm, ZjState &st,
+                                                     uint32_t end, ZjIndexOut *io, uint32_t *col)
+{
+    uint32_t nblk = 0;
+    ZjBitsLds bits;
+    bits.col = col;
+    bool first = true;
+    run = run && st.p < end;
+    while (__any(run)) {
+        if (run) {
+            const uint32_t win = st.p / ZJ_WIN_BITS;
+            zj_stage_window(stream, win * ZJ_WIN_WORDS, col);
+            bits.wbase = win * ZJ_WIN_WORDS;
+            if (first) { bits.init(st.p); first = false; }
+            const uint32_t wend = (win + 1u) * ZJ_WIN_BITS;
+            nblk += zj_decode_run<ZjBitsLds, INDEX>(bits, lut, canon, selw, bpm, st, wend < end ? wend : end, io);
+            run = st.p < end;
+        }
+    }
+    return nblk;
+}
+
 // ---------------------------------------------------------------------------------- k0: unstuff
 // One wavefront per segment.  Walks the raw bytes in 1 KiB tiles (16 bytes per lane), drops every 00
 // that follows an FF, and appends the kept bytes to an LDS buffer that is flushed in aligned
@@ -159,13 +239,16 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
     __shared__ uint32_t sinfo_lds[4][64];
+    __shared__ uint32_t win[4][ZJ_WIN_SLOTS * 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t *col = &win[wave][lane];
     const uint32_t chunk = blockIdx.x * 4u + wave;
     const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
     const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
     load_lut_to_lds(lut, P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
     ZjSel sel = {im.bpm, im.dcsel, im.acsel};
+    const uint32_t selw = zj_selword(sel);
     __syncthreads();
 
     const uint32_t seg = P.chunk_seg[chunk];
@@ -185,9 +268,11 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
         if (sub_active(sg, jl, SB, pay)) {
             done = false;
             st.p = jl * SB;
-            uint32_t n = zj_decode_span<false>(stream, lut, canon, sel, st, sub_end(jl, SB, pay), nullptr);
-            info = zj_pack_info(st, (jl + 1u) * SB, n);
         }
+    }
+    {
+        uint32_t n = zj_span_windowed<false>(!done, stream, lut, canon, selw, sel.bpm, st, done ? 0u : sub_end(jl, SB, pay), nullptr, col);
+        if (!done) info = zj_pack_info(st, (jl + 1u) * SB, n);
     }
     si[lane] = info;
     // rounds: lane i walks subsequence i+k from the state it carries
@@ -196,8 +281,8 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
         const bool act = !done && tgt < 64u && sub_active(sg, jl + k, SB, pay);
         if (!act) done = true;
         if (!__any(act)) break;
+        const uint32_t n = zj_span_windowed<false>(act, stream, lut, canon, selw, sel.bpm, st, act ? sub_end(jl + k, SB, pay) : 0u, nullptr, col);
         if (act) {
-            uint32_t n = zj_decode_span<false>(stream, lut, canon, sel, st, sub_end(jl + k, SB, pay), nullptr);
             uint32_t nw = zj_pack_info(st, (jl + k + 1u) * SB, n);
             uint32_t old = si[tgt];
             si[tgt] = nw;
@@ -263,29 +348,34 @@ __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
 __global__ __launch_bounds__(256) void zj_k1i_index(ZjParams P)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
+    __shared__ uint32_t win[4][ZJ_WIN_SLOTS * 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t *col = &win[wave][lane];
     const uint32_t chunk = blockIdx.x * 4u + wave;
     const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
     const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
     load_lut_to_lds(lut, P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
     ZjSel sel = {im.bpm, im.dcsel, im.acsel};
+    const uint32_t selw = zj_selword(sel);
     __syncthreads();
     const uint32_t seg = P.chunk_seg[chunk];
-    if (seg == ZJ_NONE) return;
+    if (seg == ZJ_NONE) return; // wave-uniform
     const ZjSegDev sg = P.segs[seg];
     const uint32_t SB = P.subbits;
     const uint32_t pay = P.seg_payload_bits[seg];
     const size_t j = (size_t)chunk * 64u + lane;
     const uint32_t jl = (uint32_t)(j - sg.first_sub);
-    if (!sub_active(sg, jl, SB, pay)) return;
+    const bool act = sub_active(sg, jl, SB, pay);
     const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
     ZjState st = {0, 0, 0};
-    if (jl > 0) st = zj_unpack_state(P.sinfo[j - 1u], jl * SB);
-    ZjIndexOut io = {P.blockpos + sg.first_block, P.dcdiff + sg.first_block, P.base[j], sg.nblocks};
-    uint32_t n = zj_decode_span<true>(stream, lut, canon, sel, st, sub_end(jl, SB, pay), &io);
-    uint32_t nw = zj_pack_info(st, (jl + 1u) * SB, n);
-    if (nw != P.sinfo[j]) atomicOr(&P.flags[1], 1u); // the chain of records is not consistent yet
+    if (act && jl > 0) st = zj_unpack_state(P.sinfo[j - 1u], jl * SB);
+    ZjIndexOut io = {P.blockpos + sg.first_block, P.dcdiff + sg.first_block, act ? P.base[j] : 0u, sg.nblocks};
+    uint32_t n = zj_span_windowed<true>(act, stream, lut, canon, selw, sel.bpm, st, act ? sub_end(jl, SB, pay) : 0u, &io, col);
+    if (act) {
+        uint32_t nw = zj_pack_info(st, (jl + 1u) * SB, n);
+        if (nw != P.sinfo[j]) atomicOr(&P.flags[1], 1u); // the chain of records is not consistent yet
+    }
 }
 
 // ---------------------------------------------------------------------------------- k1d: DC scan

@@ -142,10 +142,11 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
 
     b->imgs.resize(n);
     b->unsupported.assign(n, 0);
-    std::vector<uint32_t> chunk_seg, blk256_img, strip_img;
+    std::vector<uint32_t> chunk_seg, blk256_img;
+    std::vector<uint32_t> k2_grp[4], k2_img[4]; // stage-2 workgroups per sampling layout
     std::vector<uint16_t> luts;
     std::vector<ZjCanon> canons;
-    std::vector<uint8_t> qts;
+    std::vector<uint16_t> qts;
     std::map<std::string, uint32_t> lut_ids, qt_ids;
     std::vector<size_t> raw_off(n, 0);
     size_t raw_total = 0, ust_total = 0;
@@ -204,7 +205,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             auto it = qt_ids.find(key);
             if (it == qt_ids.end()) {
                 it = qt_ids.emplace(key, (uint32_t)qts.size()).first;
-                qts.insert(qts.end(), key.begin(), key.end());
+                for (int z = 0; z < 64; z++) qts.push_back((uint16_t)(uint8_t)key[z]);
             }
             d.qt_off[c] = it->second;
         }
@@ -259,8 +260,9 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
         nblk_total += nb_pad;
         const uint32_t T = 96 / d.bpm;
         d.strips_x = (d.mcux + T - 1) / T;
-        const uint32_t ns = d.strips_x * d.mcuy;
-        for (uint32_t s = 0; s < ns; s++) strip_img.push_back((uint32_t)i);
+        const uint32_t ns = (d.strips_x * d.mcuy + ZJ_K2_NS - 1) / ZJ_K2_NS; // workgroups of stage 2
+        const int cls = (d.hs == 2 && d.vs == 2) ? 0 : (d.hs == 1 && d.vs == 1) ? 1 : (d.hs == 2) ? 2 : 3;
+        for (uint32_t s = 0; s < ns; s++) { k2_grp[cls].push_back(s); k2_img[cls].push_back((uint32_t)i); }
         nstrip_total += ns;
         b->scan_bytes += im.scan_len;
         b->coef_bytes += (uint64_t)d.nblocks * 128;
@@ -275,7 +277,15 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.segs = dev_upload(b, b->segs);
     P.chunk_seg = dev_upload(b, chunk_seg);
     P.blk256_img = dev_upload(b, blk256_img);
-    P.strip_img = dev_upload(b, strip_img);
+    std::vector<uint32_t> strip_grp_all, strip_img_all;
+    for (int c = 0; c < 4; c++) {
+        b->L.k2_first[c] = (uint32_t)strip_grp_all.size();
+        b->L.k2_count[c] = (uint32_t)k2_grp[c].size();
+        strip_grp_all.insert(strip_grp_all.end(), k2_grp[c].begin(), k2_grp[c].end());
+        strip_img_all.insert(strip_img_all.end(), k2_img[c].begin(), k2_img[c].end());
+    }
+    P.strip_img = dev_upload(b, strip_grp_all);
+    P.strip_img_img = dev_upload(b, strip_img_all);
     P.luts = dev_upload(b, luts);
     P.canons = dev_upload(b, canons);
     P.qts = dev_upload(b, qts);
@@ -298,7 +308,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.rgb_stride = b->d_stride;
     P.nchunks = (uint32_t)chunk_seg.size();
     P.subbits = subbits;
-    ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.strip_img && P.luts && P.canons && P.qts && raw && P.ust &&
+    ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.strip_img && P.strip_img_img && P.luts && P.canons && P.qts && raw && P.ust &&
          P.seg_payload_bits && P.seg_found && P.sinfo && P.base && P.blockpos && P.dcdiff && P.dcabs && P.qcoef && P.status &&
          P.flags && b->d_rgb && b->d_stride;
     if (ok) ok = hip_ok(ctx, hipHostMalloc((void **)&b->h_rgb, (n ? n : 1) * sizeof(uint8_t *), hipHostMallocDefault), "hipHostMalloc") &&
@@ -318,7 +328,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     b->L.nseg = (uint32_t)b->segs.size();
     b->L.nchunks = P.nchunks;
     b->L.nblk256 = (uint32_t)blk256_img.size();
-    b->L.nstrips = (uint32_t)strip_img.size();
+    b->L.nstrips = (uint32_t)strip_grp_all.size();
     b->L.fix_iters = 1;
     return b;
 }
@@ -352,7 +362,7 @@ extern "C" int zj_batch_decode(zj_batch *b, uint8_t *const *rgb, const size_t *s
     }
     zj_launch_stage1(b->P, b->L, st, ev);
     ZjLaunch L2 = b->L;
-    if (!any_rgb) L2.nstrips = 0;
+    if (!any_rgb) { L2.nstrips = 0; for (int c = 0; c < 4; c++) L2.k2_count[c] = 0; }
     zj_launch_stage2(b->P, L2, st, ev ? ev + 8 : nullptr);
     if (!hip_ok(c, hipGetLastError(), "kernel launch")) return ZJ_E_DEVICE;
     b->decoded = true;
@@ -383,7 +393,7 @@ extern "C" int zj_batch_finish(zj_batch *b, uint32_t *status)
             bool any_rgb = false;
             for (size_t i = 0; i < b->n; i++) any_rgb = any_rgb || b->h_rgb[i];
             ZjLaunch L2 = b->L;
-            if (!any_rgb) L2.nstrips = 0;
+            if (!any_rgb) { L2.nstrips = 0; for (int c = 0; c < 4; c++) L2.k2_count[c] = 0; }
             zj_launch_stage2(b->P, L2, st, nullptr);
             if (!hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
             if (!hip_ok(c, hipMemcpy(b->h_flags, b->P.flags, 16, hipMemcpyDeviceToHost), "D2H flags")) return ZJ_E_DEVICE;

@@ -58,7 +58,7 @@ struct ZjImgDev {
     uint32_t dcsel;         // bit k: DC table id of block k inside the MCU
     uint32_t acsel;         // bit k: AC table id of block k inside the MCU
     uint32_t compsel;       // 2 bits per block k: component of block k
-    uint32_t qt_off[3];     // byte offsets of the three components' quantisation tables (64 B each)
+    uint32_t qt_off[3];     // element offsets of the three components' quantisation tables (64 entries each)
     uint32_t first_strip;   // first global strip index of stage 2
     uint32_t strips_x;      // strips per MCU row
     uint32_t flags;         // bit 0: supported

@@ -34,9 +34,10 @@ struct ZjParams {
     int16_t *qcoef;             // [block][64] zig-zag, quantised: the stage seam
     const uint16_t *luts;       // [table set][ZJ_SET_ENTRIES]
     const ZjCanon *canons;      // [table set][4]
-    const uint8_t *qts;         // quantisation tables, 64 bytes each, zig-zag order
+    const uint16_t *qts;        // quantisation tables widened to 16 bits, 64 entries each, zig-zag order
     const uint32_t *blk256_img; // [block / 256] image
-    const uint32_t *strip_img;  // [strip] image
+    const uint32_t *strip_img;     // [stage-2 workgroup] index of its strip group inside its image
+    const uint32_t *strip_img_img; // [stage-2 workgroup] image
     uint32_t *status;           // [image]
     uint32_t *flags;            // [0] fix pass ran through a whole chunk, [1] record chain inconsistent
     uint8_t *const *rgb;        // [image] device pointers
@@ -45,8 +46,11 @@ struct ZjParams {
     uint32_t subbits;
 };
 
+#define ZJ_K2_NS 4 // strips per workgroup of the IDCT/colour kernel
+
 struct ZjLaunch {
     uint32_t nseg, nchunks, nblk256, nstrips;
+    uint32_t k2_first[4], k2_count[4]; // stage-2 workgroups per sampling layout (2x2, 1x1, 2x1, 1x2)
     int fix_iters;
 };
 

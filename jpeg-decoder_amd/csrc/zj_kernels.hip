@@ -513,182 +513,250 @@ __device__ __forceinline__ void zj_idct_1d(const float (&in)[8], float (&out)[8]
     }
 }
 
-// Rust `as u8` (src/decoder.rs:275-277): truncate toward zero, saturate, NaN -> 0.
-__device__ __forceinline__ uint32_t zj_f32_as_u8(float v)
+// Rust `as u8` (src/decoder.rs:275-277): truncate toward zero, saturate, NaN -> 0, packed into byte
+// `pos` of `old`.  v_cvt_pk_u8_f32 saturates to 0..255, maps NaN to 0 and rounds to nearest even, so
+// the value is truncated first (an integral value is unaffected by the rounding mode).
+__device__ __forceinline__ uint32_t zj_pack_u8(float v, uint32_t pos, uint32_t old)
 {
-    v = fmaxf(v, 0.0f); // NaN -> 0
-    v = fminf(v, 255.0f);
-    return (uint32_t)(int)v;
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(v), pos, old);
 }
 
-// Natural index of the zig-zag positions 8*part .. 8*part+7, six bits each (inverse of the table at
-// src/decoder.rs:114-124).
-__constant__ uint64_t zj_zz2nat_packed[8] = {
-    // filled from the walk below at load time would need host code; the values are the zig-zag scan
-    // order of T.81 Figure A.6 grouped by eight.
-    (0ull) | (1ull << 6) | (8ull << 12) | (16ull << 18) | (9ull << 24) | (2ull << 30) | (3ull << 36) | (10ull << 42),
-    (17ull) | (24ull << 6) | (32ull << 12) | (25ull << 18) | (18ull << 24) | (11ull << 30) | (4ull << 36) | (5ull << 42),
-    (12ull) | (19ull << 6) | (26ull << 12) | (33ull << 18) | (40ull << 24) | (48ull << 30) | (41ull << 36) | (34ull << 42),
-    (27ull) | (20ull << 6) | (13ull << 12) | (6ull << 18) | (7ull << 24) | (14ull << 30) | (21ull << 36) | (28ull << 42),
-    (35ull) | (42ull << 6) | (49ull << 12) | (56ull << 18) | (57ull << 24) | (50ull << 30) | (43ull << 36) | (36ull << 42),
-    (29ull) | (22ull << 6) | (15ull << 12) | (23ull << 18) | (30ull << 24) | (37ull << 30) | (44ull << 36) | (51ull << 42),
-    (58ull) | (59ull << 6) | (52ull << 12) | (45ull << 18) | (38ull << 24) | (31ull << 30) | (39ull << 36) | (46ull << 42),
-    (53ull) | (60ull << 6) | (61ull << 12) | (54ull << 18) | (47ull << 24) | (55ull << 30) | (62ull << 36) | (63ull << 42),
+// Byte offset (4 * natural index) of the zig-zag positions 8*part .. 8*part+7, one byte each: the
+// inverse of the table at src/decoder.rs:114-124, i.e. the zig-zag scan order of T.81 Figure A.6.
+#define ZJ_NAT8(a, b, c, d, e, f, g, h)                                                                            \
+    ((uint64_t)(4 * a) | ((uint64_t)(4 * b) << 8) | ((uint64_t)(4 * c) << 16) | ((uint64_t)(4 * d) << 24) |        \
+     ((uint64_t)(4 * e) << 32) | ((uint64_t)(4 * f) << 40) | ((uint64_t)(4 * g) << 48) | ((uint64_t)(4 * h) << 56))
+__constant__ uint64_t zj_zz2nat_bytes[8] = {
+    ZJ_NAT8(0, 1, 8, 16, 9, 2, 3, 10),     ZJ_NAT8(17, 24, 32, 25, 18, 11, 4, 5),
+    ZJ_NAT8(12, 19, 26, 33, 40, 48, 41, 34), ZJ_NAT8(27, 20, 13, 6, 7, 14, 21, 28),
+    ZJ_NAT8(35, 42, 49, 56, 57, 50, 43, 36), ZJ_NAT8(29, 22, 15, 23, 30, 37, 44, 51),
+    ZJ_NAT8(58, 59, 52, 45, 38, 31, 39, 46), ZJ_NAT8(53, 60, 61, 54, 47, 55, 62, 63),
 };
 
-#define ZJ_K2_BLOCKS 96
-#define ZJ_K2_BSTRIDE 72 // floats per block in LDS: 64 + 8 keeps the column pass conflict-free
+typedef float zj_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short zj_u16x2 __attribute__((ext_vector_type(2)));
+
+#define ZJ_K2_BLOCKS 96   // blocks per strip (one workgroup pass): 16 MCUs of 4:2:0, 32 of 4:4:4, 24 of 4:2:2 / 4:4:0
+#define ZJ_K2_WBLOCKS 24  // of which each wavefront takes a quarter and works on it without workgroup barriers
+#define ZJ_K2_BSTRIDE 72  // floats per block in LDS: 64 + 8 keeps the column pass conflict-free
+// ZJ_K2_NS (zj_dev.h) strips per workgroup; the next strip's coefficients are fetched while this one computes
+
+// Order LDS accesses of the lanes of one wavefront between two phases (the wavefront runs in lock
+// step, so no barrier is needed, only that neither compiler nor hardware reorders around this point).
+__device__ __forceinline__ void zj_wave_lds_sync()
+{
+    // LDS operations of a wavefront are executed in issue order; the wait drains them, the "memory"
+    // clobber keeps the compiler from moving LDS accesses across, and global loads stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 
 template <int HS, int VS>
-__device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im, uint32_t ii, uint32_t strip,
-                                           float *blk)
+__device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im, uint32_t ii, uint32_t strip0,
+                                           uint32_t strip1, float *blk_all, const uint16_t *qlds)
 {
     constexpr int BPM = HS * VS + 2;
     constexpr int T = ZJ_K2_BLOCKS / BPM; // MCUs per strip
+    constexpr int TW = T / 4;             // MCUs per wavefront
     constexpr int MW = 8 * HS, MH = 8 * VS;
-    constexpr int ROWB = T * MW * 3;      // bytes of one pixel row of the strip
-    const uint32_t tid = threadIdx.x;
-    const uint32_t my = strip / im.strips_x, sx = strip % im.strips_x;
-    const uint32_t x0 = sx * T;
-    const uint32_t nm = min((uint32_t)T, im.mcux - x0);
-    const uint32_t nb = nm * BPM;
-    const int16_t *src = P.qcoef + ((size_t)im.first_block + ((size_t)my * im.mcux + x0) * BPM) * 64u;
-
-    // phase 1: coalesced 16-byte loads, dequantise (i16 wrapping, both operands in zig-zag order,
-    // src/decoder.rs:179-184), de-zigzag into LDS as f32 (exact), src/decoder.rs:296-300
-#pragma unroll
-    for (uint32_t i = 0; i < 3u; i++) {
-        const uint32_t q = tid + i * 256u;
-        const uint32_t b = q >> 3, part = q & 7u;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (b < nb) v = *reinterpret_cast<const uint4 *>(src + (size_t)q * 8u);
-        const uint32_t kb = b % BPM;
-        const uint32_t comp = kb < (uint32_t)(HS * VS) ? 0u : (kb == (uint32_t)(HS * VS) ? 1u : 2u);
-        const uint2 qq = *reinterpret_cast<const uint2 *>(P.qts + im.qt_off[comp] + part * 8u);
-        const uint64_t nat = zj_zz2nat_packed[part];
-        const uint32_t cw[4] = {v.x, v.y, v.z, v.w};
-        float *bp = blk + b * ZJ_K2_BSTRIDE;
-#pragma unroll
-        for (uint32_t e = 0; e < 8u; e++) {
-            int32_t c = (int16_t)(cw[e >> 1] >> (16u * (e & 1u)));
-            uint32_t qv = ((e < 4u ? qq.x : qq.y) >> (8u * (e & 3u))) & 0xFFu;
-            int16_t dq = (int16_t)(c * (int32_t)qv);
-            bp[(uint32_t)(nat >> (6u * e)) & 63u] = (float)dq;
-        }
-    }
-    __syncthreads();
-    // phase 2: 1-D IDCT over the columns of every block, in place (src/dct.rs:104-111)
-#pragma unroll
-    for (uint32_t i = 0; i < 3u; i++) {
-        const uint32_t q = tid + i * 256u;
-        const uint32_t b = q >> 3, col = q & 7u;
-        float *bp = blk + b * ZJ_K2_BSTRIDE + col;
-        float in[8], out[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) in[k] = bp[k * 8];
-        zj_idct_1d(in, out);
-#pragma unroll
-        for (int n = 0; n < 8; n++) bp[n * 8] = out[n];
-    }
-    __syncthreads();
-    // phase 3: 1-D IDCT over the rows (src/dct.rs:113-120), +128, replicate chroma, colour
-    // (src/decoder.rs:306-312).  One lane per (pixel row r, MCU m) of the strip.
-    constexpr int NTASK = T * MH;
-    constexpr int NIT = (NTASK + 255) / 256;
-    uint32_t px[NIT][MW * 3 / 4];
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const uint32_t q = tid + it * 256u;
-        const uint32_t m = q / MH, r = q % MH;
-        uint8_t bytes[MW * 3];
-        if (q < (uint32_t)NTASK) {
-            float cb[8], cr[8], in[8];
-            const float *cbp = blk + (m * BPM + HS * VS) * ZJ_K2_BSTRIDE + (r / VS) * 8u;
-#pragma unroll
-            for (int k = 0; k < 8; k++) in[k] = cbp[k];
-            zj_idct_1d(in, cb);
-#pragma unroll
-            for (int k = 0; k < 8; k++) in[k] = cbp[ZJ_K2_BSTRIDE + k];
-            zj_idct_1d(in, cr);
-#pragma unroll
-            for (int u = 0; u < HS; u++) {
-                float yv[8];
-                const float *yp = blk + (m * BPM + (r / 8u) * HS + u) * ZJ_K2_BSTRIDE + (r % 8u) * 8u;
-#pragma unroll
-                for (int k = 0; k < 8; k++) in[k] = yp[k];
-                zj_idct_1d(in, yv);
-#pragma unroll
-                for (int x = 0; x < 8; x++) {
-                    const int cx = (u * 8 + x) / HS;
-                    const float y = yv[x] + 128.0f;
-                    const float cbv = cb[cx] + 128.0f;
-                    const float crv = cr[cx] + 128.0f;
-                    // src/decoder.rs:271-273: separate multiplies and adds, left to right
-                    const float rr = 1.402f * (crv - 128.0f) + y;
-                    const float gg = -0.71414f * (crv - 128.0f) + -0.34414f * (cbv - 128.0f) + y;
-                    const float bb = 1.772f * (cbv - 128.0f) + y;
-                    bytes[(u * 8 + x) * 3 + 0] = (uint8_t)zj_f32_as_u8(rr);
-                    bytes[(u * 8 + x) * 3 + 1] = (uint8_t)zj_f32_as_u8(gg);
-                    bytes[(u * 8 + x) * 3 + 2] = (uint8_t)zj_f32_as_u8(bb);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < MW * 3; i++) bytes[i] = 0;
-        }
-#pragma unroll
-        for (int w4 = 0; w4 < MW * 3 / 4; w4++)
-            px[it][w4] = (uint32_t)bytes[4 * w4] | ((uint32_t)bytes[4 * w4 + 1] << 8) | ((uint32_t)bytes[4 * w4 + 2] << 16) |
-                         ((uint32_t)bytes[4 * w4 + 3] << 24);
-    }
-    __syncthreads();
-    // phase 4: RGB rows of the strip into LDS (reusing the block area), then one linear, coalesced
-    // copy per pixel row (src/decoder.rs:314-315 writes the same bytes pixel by pixel)
-    uint32_t *stage = reinterpret_cast<uint32_t *>(blk);
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const uint32_t q = tid + it * 256u;
-        const uint32_t m = q / MH, r = q % MH;
-        if (q < (uint32_t)NTASK) {
-            uint32_t *d = stage + (r * ROWB + m * MW * 3) / 4;
-#pragma unroll
-            for (int w4 = 0; w4 < MW * 3 / 4; w4++) d[w4] = px[it][w4];
-        }
-    }
-    __syncthreads();
+    constexpr int ROWB = TW * MW * 3;     // bytes of one pixel row of the wavefront's tile
+    constexpr int ROWP = ROWB + 16;       // row pitch of the staged rows: spreads the rows over the banks
+    constexpr int NTASK = TW * MH;        // (pixel row, MCU) pairs of the tile
+    constexpr int NIT = (NTASK + 63) / 64;
+    constexpr int NW = MW * 3 / 4;        // packed RGB words per lane and task
+    constexpr int PIECES = ROWB / 16;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float *blk = blk_all + wave * (ZJ_K2_WBLOCKS * ZJ_K2_BSTRIDE);
     uint8_t *rgb = P.rgb[ii];
     if (rgb == nullptr) return;
     const size_t stride = P.rgb_stride[ii] ? P.rgb_stride[ii] : (size_t)im.w * 3u;
-    const uint32_t row_valid = min((uint32_t)ROWB, (im.w - min(im.w, x0 * MW)) * 3u); // bytes inside the image
-    const uint32_t rows_valid = min((uint32_t)MH, im.h - min(im.h, my * MH));
     const bool vec_ok = (((uintptr_t)rgb | stride) & 15u) == 0;
-    constexpr int PIECES = ROWB / 16;
-    for (uint32_t q = tid; q < (uint32_t)(PIECES * MH); q += 256u) {
-        const uint32_t r = q / PIECES, pc = q % PIECES;
-        if (r >= rows_valid) continue;
-        const uint32_t off = pc * 16u;
-        if (off >= row_valid) continue;
-        uint8_t *dst = rgb + (size_t)(my * MH + r) * stride + (size_t)x0 * MW * 3u + off;
-        const uint32_t *s4 = stage + (r * ROWB + off) / 4;
-        if (vec_ok && off + 16u <= row_valid) {
-            *reinterpret_cast<uint4 *>(dst) = make_uint4(s4[0], s4[1], s4[2], s4[3]);
-        } else {
-            const uint32_t nbytes = min(16u, row_valid - off);
-            for (uint32_t i = 0; i < nbytes; i++) dst[i] = (uint8_t)(s4[i >> 2] >> (8u * (i & 3u)));
+
+    const uint32_t part = lane & 7u; // a lane keeps the same eighth of a block in all its tasks
+    uint32_t off[8];
+    {
+        const uint64_t natb = zj_zz2nat_bytes[part];
+#pragma unroll
+        for (int e = 0; e < 8; e++) off[e] = (uint32_t)(natb >> (8 * e)) & 0xFFu;
+    }
+    // quantisation values of this lane's eighth, per component, two 16-bit values per word
+    const uint4 *qpart = reinterpret_cast<const uint4 *>(qlds) + part;
+
+    auto strip_src = [&](uint32_t strip, uint32_t &nbw) -> const int16_t * {
+        const uint32_t my = strip / im.strips_x, sx = strip % im.strips_x;
+        const uint32_t x0 = sx * T + wave * TW; // first MCU of this wavefront
+        const uint32_t nm = x0 < im.mcux ? min((uint32_t)TW, im.mcux - x0) : 0u;
+        nbw = nm * BPM;
+        return P.qcoef + ((size_t)im.first_block + ((size_t)my * im.mcux + x0) * BPM) * 64u;
+    };
+    auto load3 = [&](const int16_t *src, uint32_t nbw, uint4 (&v)[3]) {
+#pragma unroll
+        for (uint32_t i = 0; i < 3u; i++) {
+            const uint32_t q = lane + i * 64u;
+            v[i] = make_uint4(0, 0, 0, 0);
+            if ((q >> 3) < nbw) v[i] = *reinterpret_cast<const uint4 *>(src + (size_t)q * 8u);
         }
+    };
+
+    uint4 v[3];
+    uint32_t nbw;
+    {
+        const int16_t *src = strip_src(strip0, nbw);
+        load3(src, nbw, v);
+    }
+    for (uint32_t strip = strip0; strip < strip1; strip++) {
+        const uint32_t my = strip / im.strips_x, sx = strip % im.strips_x;
+        const uint32_t x0 = sx * T + wave * TW;
+        // phase 1: dequantise (i16 wrapping, both operands in zig-zag order, src/decoder.rs:179-184) two
+        // coefficients per instruction, de-zigzag into LDS as f32 (exact), src/decoder.rs:296-300
+#pragma unroll
+        for (uint32_t i = 0; i < 3u; i++) {
+            const uint32_t b = (lane + i * 64u) >> 3;
+            const uint32_t kb = b % BPM;
+            const uint32_t comp = kb < (uint32_t)(HS * VS) ? 0u : (kb == (uint32_t)(HS * VS) ? 1u : 2u);
+            const uint4 qv = qpart[comp * 8u];
+            const uint32_t cw[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+            char *bp = reinterpret_cast<char *>(blk + b * ZJ_K2_BSTRIDE);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const zj_u16x2 pr = __builtin_bit_cast(zj_u16x2, cw[j]) * __builtin_bit_cast(zj_u16x2, qw[j]);
+                *reinterpret_cast<float *>(bp + off[2 * j]) = (float)(int16_t)pr.x;
+                *reinterpret_cast<float *>(bp + off[2 * j + 1]) = (float)(int16_t)pr.y;
+            }
+        }
+        // fetch the next strip's coefficients now; they are consumed in the next iteration
+        if (strip + 1 < strip1) {
+            const int16_t *src = strip_src(strip + 1, nbw);
+            load3(src, nbw, v);
+        }
+        zj_wave_lds_sync();
+        // phase 2: 1-D IDCT over the columns of every block, in place (src/dct.rs:104-111)
+#pragma unroll
+        for (uint32_t i = 0; i < 3u; i++) {
+            const uint32_t q = lane + i * 64u;
+            const uint32_t b = q >> 3, col = q & 7u;
+            float *bp = blk + b * ZJ_K2_BSTRIDE + col;
+            float in[8], out[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) in[k] = bp[k * 8];
+            zj_idct_1d(in, out);
+#pragma unroll
+            for (int n = 0; n < 8; n++) bp[n * 8] = out[n];
+        }
+        zj_wave_lds_sync();
+        // phase 3: 1-D IDCT over the rows (src/dct.rs:113-120), +128, replicate chroma, colour
+        // (src/decoder.rs:306-312).  One lane per (pixel row r, MCU m) of the tile.
+        uint32_t px[NIT][NW];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const uint32_t q = lane + it * 64u;
+            const uint32_t m = q / MH, r = q % MH;
+#pragma unroll
+            for (int w4 = 0; w4 < NW; w4++) px[it][w4] = 0;
+            if (q < (uint32_t)NTASK) {
+                float cb[8], cr[8], in[8];
+                const float *cbp = blk + (m * BPM + HS * VS) * ZJ_K2_BSTRIDE + (r / VS) * 8u;
+#pragma unroll
+                for (int k = 0; k < 8; k++) in[k] = cbp[k];
+                zj_idct_1d(in, cb);
+#pragma unroll
+                for (int k = 0; k < 8; k++) in[k] = cbp[ZJ_K2_BSTRIDE + k];
+                zj_idct_1d(in, cr);
+                // per chroma sample: the products of src/decoder.rs:271-273, computed once and shared by the
+                // pixels that replicate the sample.  (x + 128) - 128 is kept as two operations.
+                float pr[8], pg[8], pb[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const float cbd = (cb[c] + 128.0f) - 128.0f;
+                    const float crd = (cr[c] + 128.0f) - 128.0f;
+                    pr[c] = 1.402f * crd;
+                    pg[c] = -0.71414f * crd + -0.34414f * cbd;
+                    pb[c] = 1.772f * cbd;
+                }
+#pragma unroll
+                for (int u = 0; u < HS; u++) {
+                    float yv[8];
+                    const float *yp = blk + (m * BPM + (r / 8u) * HS + u) * ZJ_K2_BSTRIDE + (r % 8u) * 8u;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) in[k] = yp[k];
+                    zj_idct_1d(in, yv);
+#pragma unroll
+                    for (int x = 0; x < 8; x += 2) {
+                        const int cx0 = (u * 8 + x) / HS, cx1 = (u * 8 + x + 1) / HS;
+                        const zj_f32x2 y2 = zj_f32x2{yv[x], yv[x + 1]} + zj_f32x2{128.0f, 128.0f};
+                        const zj_f32x2 r2 = zj_f32x2{pr[cx0], pr[cx1]} + y2;
+                        const zj_f32x2 g2 = zj_f32x2{pg[cx0], pg[cx1]} + y2;
+                        const zj_f32x2 b2 = zj_f32x2{pb[cx0], pb[cx1]} + y2;
+                        const int o = (u * 8 + x) * 3; // byte offset of the pair inside the lane's run
+                        px[it][(o + 0) >> 2] = zj_pack_u8(r2.x, (o + 0) & 3, px[it][(o + 0) >> 2]);
+                        px[it][(o + 1) >> 2] = zj_pack_u8(g2.x, (o + 1) & 3, px[it][(o + 1) >> 2]);
+                        px[it][(o + 2) >> 2] = zj_pack_u8(b2.x, (o + 2) & 3, px[it][(o + 2) >> 2]);
+                        px[it][(o + 3) >> 2] = zj_pack_u8(r2.y, (o + 3) & 3, px[it][(o + 3) >> 2]);
+                        px[it][(o + 4) >> 2] = zj_pack_u8(g2.y, (o + 4) & 3, px[it][(o + 4) >> 2]);
+                        px[it][(o + 5) >> 2] = zj_pack_u8(b2.y, (o + 5) & 3, px[it][(o + 5) >> 2]);
+                    }
+                }
+            }
+        }
+        zj_wave_lds_sync();
+        // phase 4: RGB rows of the tile into LDS (reusing the block area), then a linear copy per pixel
+        // row in 16-byte pieces (src/decoder.rs:314-315 writes the same bytes pixel by pixel)
+        char *stage = reinterpret_cast<char *>(blk);
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const uint32_t q = lane + it * 64u;
+            const uint32_t m = q / MH, r = q % MH;
+            if (q < (uint32_t)NTASK) {
+                char *d = stage + r * ROWP + m * (MW * 3);
+                if constexpr (HS == 2) {
+#pragma unroll
+                    for (int w4 = 0; w4 < NW; w4 += 4)
+                        *reinterpret_cast<uint4 *>(d + 4 * w4) = make_uint4(px[it][w4], px[it][w4 + 1], px[it][w4 + 2], px[it][w4 + 3]);
+                } else {
+#pragma unroll
+                    for (int w4 = 0; w4 < NW; w4 += 2) *reinterpret_cast<uint2 *>(d + 4 * w4) = make_uint2(px[it][w4], px[it][w4 + 1]);
+                }
+            }
+        }
+        zj_wave_lds_sync();
+        const uint32_t xb = x0 * MW * 3u; // byte offset of the tile inside the pixel row
+        const uint32_t row_valid = min((uint32_t)ROWB, (im.w - min(im.w, x0 * MW)) * 3u); // bytes inside the image
+        const uint32_t rows_valid = min((uint32_t)MH, im.h - min(im.h, my * MH));
+        for (uint32_t q = lane; q < (uint32_t)(PIECES * MH); q += 64u) {
+            const uint32_t r = q / PIECES, pc = q % PIECES;
+            const uint32_t o = pc * 16u;
+            if (r >= rows_valid || o >= row_valid) continue;
+            uint8_t *dst = rgb + (size_t)(my * MH + r) * stride + xb + o;
+            const uint4 pv = *reinterpret_cast<const uint4 *>(stage + r * ROWP + o);
+            if (vec_ok && o + 16u <= row_valid) {
+                *reinterpret_cast<uint4 *>(dst) = pv;
+            } else {
+                const uint32_t s4[4] = {pv.x, pv.y, pv.z, pv.w};
+                const uint32_t nbytes = min(16u, row_valid - o);
+                for (uint32_t i = 0; i < nbytes; i++) dst[i] = (uint8_t)(s4[i >> 2] >> (8u * (i & 3u)));
+            }
+        }
+        zj_wave_lds_sync(); // the block area is reused by the next strip
     }
 }
 
-__global__ __launch_bounds__(256) void zj_k2_idct_rgb(ZjParams P)
+// One instantiation per sampling layout, so that each gets its own register allocation.  `first`
+// is where this layout's workgroups begin in P.strip_img.
+template <int HS, int VS>
+__global__ __launch_bounds__(256) void zj_k2_idct_rgb(ZjParams P, uint32_t first)
 {
     __shared__ __attribute__((aligned(16))) float blk[ZJ_K2_BLOCKS * ZJ_K2_BSTRIDE];
-    const uint32_t ii = P.strip_img[blockIdx.x];
+    __shared__ __attribute__((aligned(16))) uint16_t qlds[3 * 64];
+    const uint32_t grp = P.strip_img[first + blockIdx.x]; // image in the high bits is looked up below
+    const uint32_t ii = P.strip_img_img[first + blockIdx.x];
     const ZjImgDev &im = P.imgs[ii];
-    const uint32_t strip = blockIdx.x - im.first_strip;
-    if (im.hs == 2 && im.vs == 2) zj_k2_body<2, 2>(P, im, ii, strip, blk);
-    else if (im.hs == 1 && im.vs == 1) zj_k2_body<1, 1>(P, im, ii, strip, blk);
-    else if (im.hs == 2 && im.vs == 1) zj_k2_body<2, 1>(P, im, ii, strip, blk);
-    else zj_k2_body<1, 2>(P, im, ii, strip, blk);
+    if (threadIdx.x < 192u) qlds[threadIdx.x] = P.qts[im.qt_off[threadIdx.x >> 6] + (threadIdx.x & 63u)];
+    __syncthreads();
+    const uint32_t nstrips = im.strips_x * im.mcuy;
+    const uint32_t s0 = grp * ZJ_K2_NS;
+    const uint32_t s1 = min(s0 + ZJ_K2_NS, nstrips);
+    zj_k2_body<HS, VS>(P, im, ii, s0, s1, blk, qlds);
 }
 
 // ---------------------------------------------------------------------------------- export (tests)
@@ -703,7 +771,7 @@ __global__ __launch_bounds__(256) void zj_kx_dequant(ZjParams P, uint32_t ii, in
     const uint32_t comp = (im.compsel >> (2u * kb)) & 3u;
     const int32_t c = P.qcoef[(size_t)im.first_block * 64u + idx];
     const int32_t qv = P.qts[im.qt_off[comp] + zz];
-    const uint32_t nat = (uint32_t)(zj_zz2nat_packed[zz >> 3] >> (6u * (zz & 7u))) & 63u;
+    const uint32_t nat = ((uint32_t)(zj_zz2nat_bytes[zz >> 3] >> (8u * (zz & 7u))) & 0xFFu) >> 2;
     dst[(size_t)b * 64u + nat] = (int16_t)(c * qv);
 }
 
@@ -744,7 +812,11 @@ extern "C" void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipS
 
 extern "C" void zj_launch_stage2(const ZjParams &P, const ZjLaunch &L, hipStream_t st, hipEvent_t *ev)
 {
-    if (L.nstrips) hipLaunchKernelGGL(zj_k2_idct_rgb, dim3(L.nstrips), dim3(256), 0, st, P);
+    // classes: 0 = 4:2:0 (2x2), 1 = 4:4:4 (1x1), 2 = 4:2:2 (2x1), 3 = 4:4:0 (1x2)
+    if (L.k2_count[0]) hipLaunchKernelGGL((zj_k2_idct_rgb<2, 2>), dim3(L.k2_count[0]), dim3(256), 0, st, P, L.k2_first[0]);
+    if (L.k2_count[1]) hipLaunchKernelGGL((zj_k2_idct_rgb<1, 1>), dim3(L.k2_count[1]), dim3(256), 0, st, P, L.k2_first[1]);
+    if (L.k2_count[2]) hipLaunchKernelGGL((zj_k2_idct_rgb<2, 1>), dim3(L.k2_count[2]), dim3(256), 0, st, P, L.k2_first[2]);
+    if (L.k2_count[3]) hipLaunchKernelGGL((zj_k2_idct_rgb<1, 2>), dim3(L.k2_count[3]), dim3(256), 0, st, P, L.k2_first[3]);
     if (ev) hipEventRecord(ev[0], st);
 }
 

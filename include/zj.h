@@ -136,7 +136,7 @@ void zj_destroy(zj_ctx *ctx);
 const char *zj_last_error(zj_ctx *ctx);
 
 /* Tuning knob: bits per bitstream subsequence handed to one lane of the Huffman stage (a power of
- * two, 256..8192; 0 = choose from the batch size). */
+ * two, 512..8192; 0 = default). */
 #define ZJ_FLAG_SUBSEQ_BITS(b) ((uint32_t)(b))
 
 /* Plan a batch: validates the images, builds the device tables, uploads the scans, allocates all

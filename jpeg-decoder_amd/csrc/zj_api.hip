@@ -138,7 +138,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
 
     uint32_t subbits = flags & 0xFFFFu;
     if (subbits == 0) subbits = 1024;
-    if (subbits < 256 || subbits > 8192 || (subbits & (subbits - 1))) { ctx->err = "subsequence bits must be a power of two in 256..8192"; delete b; return nullptr; }
+    if (subbits < ZJ_WIN_BITS || subbits > 8192 || (subbits & (subbits - 1))) { ctx->err = "subsequence bits must be a power of two in 512..8192"; delete b; return nullptr; }
 
     b->imgs.resize(n);
     b->unsupported.assign(n, 0);
@@ -294,10 +294,9 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.ust = dev_alloc<uint8_t>(b, ust_total + 1040, true);
     P.seg_payload_bits = dev_alloc<uint32_t>(b, b->segs.size(), true);
     P.seg_found = dev_alloc<uint32_t>(b, b->segs.size(), true);
-    P.sinfo = dev_alloc<uint32_t>(b, nsub_total, true);
+    P.winfo = dev_alloc<uint32_t>(b, nsub_total * (subbits / ZJ_WIN_BITS), true);
     P.base = dev_alloc<uint32_t>(b, nsub_total, true);
     P.blockpos = dev_alloc<uint32_t>(b, nblk_total, true);
-    P.dcdiff = dev_alloc<int16_t>(b, nblk_total, true);
     P.dcabs = dev_alloc<int16_t>(b, nblk_total, true);
     P.qcoef = dev_alloc<int16_t>(b, nblk_total * 64, false);
     P.status = dev_alloc<uint32_t>(b, n, true);
@@ -308,8 +307,9 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.rgb_stride = b->d_stride;
     P.nchunks = (uint32_t)chunk_seg.size();
     P.subbits = subbits;
+    P.nc = subbits / ZJ_WIN_BITS;
     ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.strip_img && P.strip_img_img && P.luts && P.canons && P.qts && raw && P.ust &&
-         P.seg_payload_bits && P.seg_found && P.sinfo && P.base && P.blockpos && P.dcdiff && P.dcabs && P.qcoef && P.status &&
+         P.seg_payload_bits && P.seg_found && P.winfo && P.base && P.blockpos && P.dcabs && P.qcoef && P.status &&
          P.flags && b->d_rgb && b->d_stride;
     if (ok) ok = hip_ok(ctx, hipHostMalloc((void **)&b->h_rgb, (n ? n : 1) * sizeof(uint8_t *), hipHostMallocDefault), "hipHostMalloc") &&
                  hip_ok(ctx, hipHostMalloc((void **)&b->h_stride, (n ? n : 1) * sizeof(size_t), hipHostMallocDefault), "hipHostMalloc") &&

@@ -76,13 +76,23 @@ struct ZjSegDev {
     uint32_t nblocks;            // blocks coded in this segment
 };
 
-// Packed per-subsequence record ("s_info"): where the decoder stands when it crosses the end of
-// the subsequence, and how many blocks began inside it.
-//   [5:0]   overflow: bits the last symbol reaches past the nominal end (0..32)
+// Window records.  Every segment's unstuffed stream is cut into windows of ZJ_WIN_BITS bits; a
+// subsequence (the stretch one lane decodes on its own) is a run of subbits / ZJ_WIN_BITS windows.
+// The record of a window says where a decoder stands when it crosses the window's end, and how many
+// blocks began inside the window:
+//   [5:0]   overflow: bits the last symbol reaches past the window's end (0..32)
 //   [9:6]   index of the current block inside its MCU
 //   [15:10] zig-zag index inside the block (0 = a DC symbol comes next)
-//   [31:16] blocks whose DC symbol starts inside this subsequence
+//   [31:16] blocks whose DC symbol starts inside this window
+// Records of one chunk (64 subsequences) are stored [window of the subsequence][lane], so that the
+// lanes of a wavefront touch consecutive words.
+#define ZJ_WIN_WORDS 16
+#define ZJ_WIN_BITS (ZJ_WIN_WORDS * 32)
 #define ZJ_INFO_STATE_MASK 0xFFFFu
+
+// Index of the record of window c of subsequence q (both relative to the segment) inside the
+// segment's record area; nc = windows per subsequence.
+ZJ_HD uint32_t zj_rec_index(uint32_t q, uint32_t c, uint32_t nc) { return ((q >> 6) * nc + c) * 64u + (q & 63u); }
 
 struct ZjState {
     uint32_t p; // bit position inside the segment's unstuffed stream
@@ -269,6 +279,21 @@ ZJ_HD int32_t zj_extend(uint32_t nbits, uint32_t v)
     return (int32_t)(int16_t)((int32_t)(int16_t)v - maxv);
 }
 
+// DC difference of the block whose DC symbol starts at bit `p` (src/decoder.rs:194-199 without the
+// predictor): one table lookup and the EXTEND of the bits behind the code.
+ZJ_HD int32_t zj_dc_diff(const uint32_t *stream, const uint16_t *dctbl, const ZjCanon *canon, uint32_t p)
+{
+    const uint32_t w = p >> 5, sh = p & 31u;
+    const uint64_t two = ((uint64_t)zj_bswap32(stream[w]) << 32) | zj_bswap32(stream[w + 1]);
+    const uint32_t top = (uint32_t)((two << sh) >> 32);
+    const uint32_t e = zj_lookup(dctbl, canon, top);
+    const uint32_t len = (e >> 8) & 31u;
+    uint32_t s = e & 255u;
+    if (len == 0 || s > 16u) return 0; // not a code: the write pass reports it
+    const uint32_t v = s ? ((top << len) >> (32 - s)) : 0u;
+    return zj_extend(s, v);
+}
+
 struct ZjSel { // table selectors of the image a lane works on
     uint32_t bpm, dcsel, acsel;
 };
@@ -288,7 +313,6 @@ ZJ_HD uint32_t zj_selword(const ZjSel &s)
 // What a span decode records besides the state.
 struct ZjIndexOut {
     uint32_t *blockpos; // [segment block] bit position of the block's DC symbol
-    int16_t *dcdiff;    // [segment block] decoded DC difference
     uint32_t g;         // next segment-relative block index
     uint32_t glimit;    // blocks coded in the segment
 };
@@ -317,11 +341,7 @@ ZJ_HD uint32_t zj_decode_run(BITS &bits, const uint16_t *lut, const ZjCanon *can
         tot = tot ? tot : 1u;   // no such code: keep moving, the write pass reports it
         if (INDEX) {
             if (isdc) {
-                if (io->g < io->glimit) {
-                    const uint32_t v = s ? ((top << len) >> (32 - s)) : 0u;
-                    io->blockpos[io->g] = p;
-                    io->dcdiff[io->g] = (int16_t)zj_extend(s, v);
-                }
+                if (io->g < io->glimit) io->blockpos[io->g] = p;
                 io->g++;
             }
         }

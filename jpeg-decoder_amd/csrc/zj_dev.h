@@ -26,11 +26,10 @@ struct ZjParams {
     uint32_t *seg_payload_bits; // [seg] bits of unstuffed payload
     uint32_t *seg_found;        // [seg] blocks found in the payload
     const uint32_t *chunk_seg;  // [chunk of 64 subsequences] segment or ZJ_NONE
-    uint32_t *sinfo;            // [subsequence] packed record
+    uint32_t *winfo;            // [chunk][window of the subsequence][lane] window records (zj_core.h)
     uint32_t *base;             // [subsequence] blocks that begin earlier in the segment
     uint32_t *blockpos;         // [block] bit position of the block in its segment's stream
-    int16_t *dcdiff;            // [block]
-    int16_t *dcabs;             // [block]
+    int16_t *dcabs;             // [block] DC value after prediction
     int16_t *qcoef;             // [block][64] zig-zag, quantised: the stage seam
     const uint16_t *luts;       // [table set][ZJ_SET_ENTRIES]
     const ZjCanon *canons;      // [table set][4]
@@ -43,7 +42,8 @@ struct ZjParams {
     uint8_t *const *rgb;        // [image] device pointers
     const size_t *rgb_stride;   // [image]
     uint32_t nchunks;
-    uint32_t subbits;
+    uint32_t subbits;           // bits per subsequence
+    uint32_t nc;                // windows per subsequence = subbits / ZJ_WIN_BITS
 };
 
 #define ZJ_K2_NS 4 // strips per workgroup of the IDCT/colour kernel

@@ -8,9 +8,10 @@
 //                subsequences until their state meets the recorded one (self-synchronisation)
 //   k1b_fix      stitches consecutive wavefront chunks the same way, one lane per chunk boundary
 //   k1s_scan     exclusive prefix sum of blocks-per-subsequence inside each segment
-//   k1i_index    second walk from the now-known states: where every block begins and its DC
-//                difference; verifies the chain of recorded states
-//   k1d_dcscan   DC predictor = wrapping-i16 prefix sum per component      (src/decoder.rs:199-200)
+//   k1i_index    second walk from the now-known states: where every block begins; verifies the
+//                chain of recorded states
+//   k1d_dcscan   DC differences from the block positions, DC predictor = wrapping-i16 prefix sum per
+//                component                                                  (src/decoder.rs:194-200)
 //   k1w_write    one lane per block: decode the block into an LDS tile, store 64 blocks coalesced
 // Stage 2+3 (src/decoder.rs:179-184 dequantize, :137-146 de-zigzag, src/dct.rs IDCT,
 // src/decoder.rs:265-320 colour + store):
@@ -83,9 +84,7 @@ __device__ __forceinline__ void load_lut_to_lds(uint16_t *lds, const uint16_t *s
 // its own stretch in a private column of LDS -- ZJ_WIN_WORDS words plus two words of look-ahead,
 // word w of lane l at [w][l], so the column reads are bank-conflict free -- with all lanes of the
 // wavefront staging at the same moment, and the symbol loop refills from LDS.
-#define ZJ_WIN_WORDS 16
-#define ZJ_WIN_SLOTS 18
-#define ZJ_WIN_BITS (ZJ_WIN_WORDS * 32)
+#define ZJ_WIN_SLOTS (ZJ_WIN_WORDS + 2)
 
 struct ZjBitsLds {
     const uint32_t *col; // this lane's column: word slot s at col[s * 64]
@@ -94,11 +93,14 @@ struct ZjBitsLds {
     uint64_t buf;
     int32_t cnt;
 
-    __device__ __forceinline__ uint32_t take() { return __builtin_bswap32(col[(widx++ - wbase) * 64u]); }
+    __device__ __forceinline__ uint32_t peek_word() const { return col[(widx - wbase) * 64u]; }
     __device__ __forceinline__ void init(uint32_t bitpos)
     {
         widx = bitpos >> 5;
-        uint64_t w0 = take(), w1 = take();
+        uint64_t w0 = __builtin_bswap32(peek_word());
+        widx++;
+        uint64_t w1 = __builtin_bswap32(peek_word());
+        widx++;
         const uint32_t sh = bitpos & 31u;
         buf = ((w0 << 32) | w1) << sh;
         cnt = 64 - (int32_t)sh;
@@ -108,8 +110,9 @@ struct ZjBitsLds {
     {
         buf <<= n;
         cnt -= (int32_t)n;
-        if (cnt <= 32) {
-            uint64_t w = take();
+        if (cnt <= 32) { // a branch, not a select: in the later rounds of the sync pass few lanes are live
+            const uint64_t w = __builtin_bswap32(peek_word());
+            widx++;
             buf |= w << (32 - cnt);
             cnt += 32;
         }
@@ -129,30 +132,25 @@ __device__ __forceinline__ void zj_stage_window(const uint32_t *stream, uint32_t
     col[16 * 64] = e.x; col[17 * 64] = e.y;
 }
 
-// zj_decode_span for all lanes of a wavefront at once: lanes with `run` set walk [st.p, end) of their own
-// stream through staged windows.  Must be called by the whole wavefront (it votes).
+// One window for the lanes of a wavefront that have `run` set: stage window `win` (index inside the
+// segment) of the lane's stream, then walk the symbols that start before the window's end or `end`,
+// whichever comes first.  The reader carries over from window to window; `primed` says whether it has
+// been positioned yet.  Returns the number of blocks that began.
 template <bool INDEX>
-__device__ __forceinline__ uint32_t zj_span_windowed(bool run, const uint32_t *stream, const uint16_t *lut,
-                                                     const ZjCanon *canon, uint32_t selw, uint32_t bpm, ZjState &st,
-                                                     uint32_t end, ZjIndexOut *io, uint32_t *col)
+__device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *stream, const uint16_t *lut,
+                                                   const ZjCanon *canon, uint32_t selw, uint32_t bpm, ZjState &st,
+                                                   uint32_t win, uint32_t end, ZjIndexOut *io, uint32_t *col,
+                                                   ZjBitsLds &bits, bool &primed)
 {
-    uint32_t nblk = 0;
-    ZjBitsLds bits;
-    bits.col = col;
-    bool first = true;
-    run = run && st.p < end;
-    while (__any(run)) {
-        if (run) {
-            const uint32_t win = st.p / ZJ_WIN_BITS;
-            zj_stage_window(stream, win * ZJ_WIN_WORDS, col);
-            bits.wbase = win * ZJ_WIN_WORDS;
-            if (first) { bits.init(st.p); first = false; }
-            const uint32_t wend = (win + 1u) * ZJ_WIN_BITS;
-            nblk += zj_decode_run<ZjBitsLds, INDEX>(bits, lut, canon, selw, bpm, st, wend < end ? wend : end, io);
-            run = st.p < end;
-        }
+    uint32_t n = 0;
+    if (run) {
+        zj_stage_window(stream, win * ZJ_WIN_WORDS, col);
+        bits.wbase = win * ZJ_WIN_WORDS;
+        if (!primed) { bits.init(st.p); primed = true; }
+        const uint32_t wend = (win + 1u) * ZJ_WIN_BITS;
+        n = zj_decode_run<ZjBitsLds, INDEX>(bits, lut, canon, selw, bpm, st, wend < end ? wend : end, io);
     }
-    return nblk;
+    return n;
 }
 
 // ---------------------------------------------------------------------------------- k0: unstuff
@@ -235,13 +233,21 @@ __global__ __launch_bounds__(64) void zj_k0_unstuff(ZjParams P)
 
 // ---------------------------------------------------------------------------------- k1a: sync
 // 256 threads = 4 wavefronts = 4 chunks of 64 subsequences, all of one image (table set in LDS).
+// Round 0: every lane walks its own subsequence from the guessed state "a block starts here" and
+// leaves one record per window.  Round k: lane i walks on into subsequence i+k from the state it
+// carries, replacing the records it passes, until its state at a window end equals the record that is
+// already there -- from that point on the two walks coincide, so the lane is synchronised and stops.
+// The wavefront votes (ballot) on whether any lane still has to walk.  Dynamic LDS: 4 * nc * 64 words.
+extern __shared__ uint32_t zj_dyn_lds[];
+
 __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
-    __shared__ uint32_t sinfo_lds[4][64];
     __shared__ uint32_t win[4][ZJ_WIN_SLOTS * 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t NC = P.nc, SB = P.subbits;
     uint32_t *col = &win[wave][lane];
+    volatile uint32_t *wrec = zj_dyn_lds + wave * NC * 64u; // [window c][lane]
     const uint32_t chunk = blockIdx.x * 4u + wave;
     const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
     const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
@@ -249,80 +255,96 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
     ZjSel sel = {im.bpm, im.dcsel, im.acsel};
     const uint32_t selw = zj_selword(sel);
+    for (uint32_t c = 0; c < NC; c++) wrec[c * 64u + lane] = 0;
     __syncthreads();
 
     const uint32_t seg = P.chunk_seg[chunk];
-    volatile uint32_t *si = sinfo_lds[wave];
-    uint32_t info = 0;
-    bool done = true;
-    ZjSegDev sg = {};
-    uint32_t jl = 0, pay = 0;
-    const uint32_t SB = P.subbits;
-    const uint32_t *stream = nullptr;
-    ZjState st = {0, 0, 0};
-    if (seg != ZJ_NONE) {
-        sg = P.segs[seg];
-        jl = chunk * 64u + lane - sg.first_sub;
-        pay = P.seg_payload_bits[seg];
-        stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
-        if (sub_active(sg, jl, SB, pay)) {
-            done = false;
-            st.p = jl * SB;
+    if (seg == ZJ_NONE) return; // wave-uniform: a padding chunk
+    const ZjSegDev sg = P.segs[seg];
+    const uint32_t jl = chunk * 64u + lane - sg.first_sub;
+    const uint32_t pay = P.seg_payload_bits[seg];
+    const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
+    ZjBitsLds bits;
+    bits.col = col;
+    bool primed = false;
+    ZjState st = {jl * SB, 0, 0};
+    const bool act0 = sub_active(sg, jl, SB, pay);
+    {
+        const uint32_t end = act0 ? sub_end(jl, SB, pay) : 0u;
+        for (uint32_t c = 0; c < NC; c++) {
+            const bool run = act0 && st.p < end;
+            if (!__any(run)) break;
+            const uint32_t w = jl * NC + c;
+            const uint32_t n = zj_window_step<false>(run, stream, lut, canon, selw, sel.bpm, st, w, end, nullptr, col, bits, primed);
+            if (run) wrec[c * 64u + lane] = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
         }
     }
-    {
-        uint32_t n = zj_span_windowed<false>(!done, stream, lut, canon, selw, sel.bpm, st, done ? 0u : sub_end(jl, SB, pay), nullptr, col);
-        if (!done) info = zj_pack_info(st, (jl + 1u) * SB, n);
-    }
-    si[lane] = info;
-    // rounds: lane i walks subsequence i+k from the state it carries
+    bool done = !act0;
     for (uint32_t k = 1; k < 64u; k++) {
-        const uint32_t tgt = lane + k;
-        const bool act = !done && tgt < 64u && sub_active(sg, jl + k, SB, pay);
+        const uint32_t tgt = lane + k, q = jl + k;
+        bool act = !done && tgt < 64u && sub_active(sg, q, SB, pay);
         if (!act) done = true;
         if (!__any(act)) break;
-        const uint32_t n = zj_span_windowed<false>(act, stream, lut, canon, selw, sel.bpm, st, act ? sub_end(jl + k, SB, pay) : 0u, nullptr, col);
-        if (act) {
-            uint32_t nw = zj_pack_info(st, (jl + k + 1u) * SB, n);
-            uint32_t old = si[tgt];
-            si[tgt] = nw;
-            if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0u) done = true;
+        const uint32_t end = act ? sub_end(q, SB, pay) : 0u;
+        for (uint32_t c = 0; c < NC; c++) {
+            const bool run = act && st.p < end;
+            if (!__any(run)) break;
+            const uint32_t w = q * NC + c;
+            const uint32_t n = zj_window_step<false>(run, stream, lut, canon, selw, sel.bpm, st, w, end, nullptr, col, bits, primed);
+            if (run) {
+                const uint32_t nw = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
+                const uint32_t old = wrec[c * 64u + tgt];
+                wrec[c * 64u + tgt] = nw;
+                if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0u) { act = false; done = true; }
+            }
         }
     }
-    P.sinfo[(size_t)chunk * 64u + lane] = si[lane];
+    uint32_t *out = P.winfo + (size_t)chunk * 64u * NC;
+    for (uint32_t c = 0; c < NC; c++) out[c * 64u + lane] = wrec[c * 64u + lane];
 }
 
 // ---------------------------------------------------------------------------------- k1b: fix
-// One lane per chunk: starts from the state recorded at the end of the previous chunk and rewrites
-// the records of its own chunk until it meets a record that already agrees.
+// One lane per chunk: starts from the state recorded at the end of the previous chunk and replaces
+// the window records of its own chunk until it meets a record that already agrees.
 __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
 {
-    const uint32_t c = blockIdx.x * 64u + threadIdx.x;
-    if (c >= P.nchunks) return;
-    const uint32_t seg = P.chunk_seg[c];
+    const uint32_t ch = blockIdx.x * 64u + threadIdx.x;
+    if (ch >= P.nchunks) return;
+    const uint32_t seg = P.chunk_seg[ch];
     if (seg == ZJ_NONE) return;
     const ZjSegDev sg = P.segs[seg];
-    if (c * 64u == sg.first_sub) return; // the first chunk of a segment starts from the true state
-    const uint32_t SB = P.subbits;
+    if (ch * 64u == sg.first_sub) return; // the first chunk of a segment starts from the true state
+    const uint32_t SB = P.subbits, NC = P.nc;
     const uint32_t pay = P.seg_payload_bits[seg];
-    const uint32_t jl0 = c * 64u - sg.first_sub;
-    if (!sub_active(sg, jl0, SB, pay)) return;
+    const uint32_t q0 = ch * 64u - sg.first_sub;
+    if (!sub_active(sg, q0, SB, pay)) return;
     const ZjImgDev &im = P.imgs[sg.img];
     const uint16_t *lut = P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES;
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
     ZjSel sel = {im.bpm, im.dcsel, im.acsel};
+    const uint32_t selw = zj_selword(sel);
     const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
-    ZjState st = zj_unpack_state(P.sinfo[(size_t)c * 64u - 1u], jl0 * SB);
+    uint32_t *rec = P.winfo + (size_t)sg.first_sub * NC;
+    ZjState st = zj_unpack_state(rec[zj_rec_index(q0 - 1u, NC - 1u, NC)], q0 * SB);
+    ZjBits bits;
+    bits.init(stream, st.p);
     for (uint32_t t = 0; t < 64u; t++) {
-        const uint32_t q = jl0 + t;
-        if (!sub_active(sg, q, SB, pay)) break;
-        uint32_t n = zj_decode_span<false>(stream, lut, canon, sel, st, sub_end(q, SB, pay), nullptr);
-        uint32_t nw = zj_pack_info(st, (q + 1u) * SB, n);
-        uint32_t old = P.sinfo[(size_t)c * 64u + t];
-        P.sinfo[(size_t)c * 64u + t] = nw;
-        if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0u) break;
-        if (t == 63u) atomicOr(&P.flags[0], 1u); // ran through the whole chunk: the next one may be stale
+        const uint32_t q = q0 + t;
+        if (!sub_active(sg, q, SB, pay)) return;
+        const uint32_t end = sub_end(q, SB, pay);
+        for (uint32_t c = 0; c < NC; c++) {
+            if (st.p >= end) break;
+            const uint32_t w = q * NC + c;
+            const uint32_t wend = (w + 1u) * ZJ_WIN_BITS;
+            const uint32_t n = zj_decode_run<ZjBits, false>(bits, lut, canon, selw, sel.bpm, st, wend < end ? wend : end, nullptr);
+            const uint32_t nw = zj_pack_info(st, wend, n);
+            const uint32_t idx = zj_rec_index(q, c, NC);
+            const uint32_t old = rec[idx];
+            rec[idx] = nw;
+            if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0u) return;
+        }
     }
+    atomicOr(&P.flags[0], 1u); // ran through the whole chunk: the next one may have started from a stale state
 }
 
 // ---------------------------------------------------------------------------------- k1s: scan
@@ -332,10 +354,14 @@ __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
     __shared__ uint32_t wsum[8];
     const uint32_t s = blockIdx.x;
     const ZjSegDev sg = P.segs[s];
+    const uint32_t NC = P.nc;
+    const uint32_t *rec = P.winfo + (size_t)sg.first_sub * NC;
     uint32_t carry = 0;
     for (uint32_t t0 = 0; t0 < sg.nsub; t0 += 256u) {
         const uint32_t q = t0 + threadIdx.x;
-        uint32_t n = q < sg.nsub ? (P.sinfo[(size_t)sg.first_sub + q] >> 16) : 0u;
+        uint32_t n = 0;
+        if (q < sg.nsub)
+            for (uint32_t c = 0; c < NC; c++) n += rec[zj_rec_index(q, c, NC)] >> 16;
         uint32_t total;
         uint32_t inc = block_incl_scan<4>(n, wsum, &total);
         if (q < sg.nsub) P.base[(size_t)sg.first_sub + q] = carry + inc - n;
@@ -362,20 +388,51 @@ __global__ __launch_bounds__(256) void zj_k1i_index(ZjParams P)
     const uint32_t seg = P.chunk_seg[chunk];
     if (seg == ZJ_NONE) return; // wave-uniform
     const ZjSegDev sg = P.segs[seg];
-    const uint32_t SB = P.subbits;
+    const uint32_t SB = P.subbits, NC = P.nc;
     const uint32_t pay = P.seg_payload_bits[seg];
     const size_t j = (size_t)chunk * 64u + lane;
     const uint32_t jl = (uint32_t)(j - sg.first_sub);
     const bool act = sub_active(sg, jl, SB, pay);
     const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
-    ZjState st = {0, 0, 0};
-    if (act && jl > 0) st = zj_unpack_state(P.sinfo[j - 1u], jl * SB);
-    ZjIndexOut io = {P.blockpos + sg.first_block, P.dcdiff + sg.first_block, act ? P.base[j] : 0u, sg.nblocks};
-    uint32_t n = zj_span_windowed<true>(act, stream, lut, canon, selw, sel.bpm, st, act ? sub_end(jl, SB, pay) : 0u, &io, col);
-    if (act) {
-        uint32_t nw = zj_pack_info(st, (jl + 1u) * SB, n);
-        if (nw != P.sinfo[j]) atomicOr(&P.flags[1], 1u); // the chain of records is not consistent yet
+    const uint32_t *rec = P.winfo + (size_t)sg.first_sub * NC;
+    ZjState st = {jl * SB, 0, 0};
+    if (act && jl > 0) st = zj_unpack_state(rec[zj_rec_index(jl - 1u, NC - 1u, NC)], jl * SB);
+    ZjIndexOut io = {P.blockpos + sg.first_block, act ? P.base[j] : 0u, sg.nblocks};
+    const uint32_t end = act ? sub_end(jl, SB, pay) : 0u;
+    ZjBitsLds bits;
+    bits.col = col;
+    bool primed = false, bad = false;
+    for (uint32_t c = 0; c < NC; c++) {
+        const bool run = act && st.p < end;
+        if (!__any(run)) break;
+        const uint32_t w = jl * NC + c;
+        const uint32_t n = zj_window_step<true>(run, stream, lut, canon, selw, sel.bpm, st, w, end, &io, col, bits, primed);
+        if (run && zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n) != rec[zj_rec_index(jl, c, NC)]) bad = true;
     }
+    if (bad) atomicOr(&P.flags[1], 1u); // the chain of records is not consistent yet
+}
+
+// ---------------------------------------------------------------------------------- k1c: DC differences
+// One lane per block: decode the DC symbol at the recorded block position (src/decoder.rs:194-199
+// without the predictor).  Fully parallel; the tables are read through the cache.
+__global__ __launch_bounds__(256) void zj_k1c_dcdiff(ZjParams P)
+{
+    const uint32_t ii = P.blk256_img[blockIdx.x];
+    const ZjImgDev &im = P.imgs[ii];
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t gl = g - im.first_block;
+    if (gl >= im.nblocks) return;
+    const uint32_t segi = im.ri_blocks ? gl / im.ri_blocks : 0u;
+    const uint32_t seg = im.first_seg + segi;
+    const uint32_t gs = gl - segi * im.ri_blocks;
+    int32_t d = 0;
+    if (gs < P.seg_found[seg]) {
+        const uint32_t t = (im.dcsel >> (gs % im.bpm)) & 1u;
+        const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[seg].out_off);
+        d = zj_dc_diff(stream, P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES + t * ZJ_TBL_ENTRIES,
+                       P.canons + (size_t)im.lut_set * 4u + t, P.blockpos[g]);
+    }
+    P.dcabs[g] = (int16_t)d; // turned into the predicted value in place by the scan
 }
 
 // ---------------------------------------------------------------------------------- k1d: DC scan
@@ -391,8 +448,8 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan(ZjParams P)
     const uint32_t bpm = im.bpm, compsel = im.compsel;
     const uint32_t found = min(P.seg_found[s], sg.nblocks);
     const uint32_t nmcu = sg.nblocks / bpm;
-    const int16_t *dd = P.dcdiff + sg.first_block;
-    int16_t *da = P.dcabs + sg.first_block;
+    int16_t *da = P.dcabs + sg.first_block; // holds the differences on entry
+    (void)found;
     uint32_t carry[3] = {0, 0, 0};
     for (uint32_t m0 = 0; m0 < nmcu; m0 += 256u) {
         const uint32_t m = m0 + threadIdx.x;
@@ -400,7 +457,7 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan(ZjParams P)
 #pragma unroll
         for (uint32_t k = 0; k < 6u; k++) {
             uint32_t g = m * bpm + k;
-            if (k < bpm && m < nmcu && g < found) d[k] = (uint32_t)(int32_t)dd[g];
+            if (k < bpm && m < nmcu) d[k] = (uint32_t)(int32_t)da[g];
             uint32_t c = (compsel >> (2u * k)) & 3u;
 #pragma unroll
             for (uint32_t cc = 0; cc < 3u; cc++)
@@ -783,7 +840,7 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     hipMemsetAsync(P.flags, 0, 16, st);
     hipLaunchKernelGGL(zj_k0_unstuff, dim3(L.nseg), dim3(64), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
-    hipLaunchKernelGGL(zj_k1a_sync, dim3(L.nchunks / 4), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(zj_k1a_sync, dim3(L.nchunks / 4), dim3(256), 4u * P.nc * 64u * sizeof(uint32_t), st, P);
     if (ev) hipEventRecord(ev[e++], st);
     for (int i = 0; i < L.fix_iters; i++) hipLaunchKernelGGL(zj_k1b_fix, dim3((L.nchunks + 63) / 64), dim3(64), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
@@ -791,6 +848,7 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1i_index, dim3(L.nchunks / 4), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
+    hipLaunchKernelGGL(zj_k1c_dcdiff, dim3(L.nblk256), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.nseg), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1w_write, dim3(L.nblk256), dim3(256), 0, st, P);
@@ -806,6 +864,7 @@ extern "C" void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipS
 {
     hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1i_index, dim3(L.nchunks / 4), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(zj_k1c_dcdiff, dim3(L.nblk256), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.nseg), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1w_write, dim3(L.nblk256), dim3(256), 0, st, P);
 }

@@ -63,22 +63,35 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
         const uint32_t *stream = (const uint32_t *)ust.data();
         const uint32_t nsub = (uint32_t)(((end - beg) * 8 + subbits - 1) / subbits);
         const uint32_t nchunk = (nsub + 63) / 64;
-        std::vector<uint32_t> sinfo(nchunk * 64 + 1, 0), base(nchunk * 64 + 1, 0);
+        const uint32_t NC = subbits / ZJ_WIN_BITS;
+        const uint32_t selw = zj_selword(sel);
+        std::vector<uint32_t> rec((size_t)nchunk * 64 * NC + 1, 0), base(nchunk * 64 + 1, 0);
         auto active = [&](uint32_t q) { return q < nsub && (uint64_t)q * subbits < pay; };
         auto send = [&](uint32_t q) { uint64_t e = (uint64_t)(q + 1) * subbits; return e < pay ? (uint32_t)e : pay; };
-        // k1a: per chunk, rounds in lock step
-        for (uint32_t c = 0; c < nchunk; c++) {
+        // one window of a walk: symbols that start before the end of window w (or `e`), on a reader that
+        // is re-positioned every time (the kernels carry the reader over; the bits are the same)
+        auto window = [&](ZjState &st, uint32_t w, uint32_t e) {
+            uint32_t wend = (w + 1) * ZJ_WIN_BITS;
+            uint32_t stop = wend < e ? wend : e;
+            if (st.p >= stop) return 0u;
+            ZjBits bits;
+            bits.init(stream, st.p);
+            return zj_decode_run<ZjBits, false>(bits, lut.data(), canon, selw, bpm, st, stop, nullptr);
+        };
+        // k1a: per chunk, rounds in lock step, one record per window
+        for (uint32_t ch = 0; ch < nchunk; ch++) {
             ZjState st[64];
             bool done[64];
             for (uint32_t l = 0; l < 64; l++) {
-                uint32_t jl = c * 64 + l;
-                done[l] = true;
-                sinfo[jl] = 0;
-                if (active(jl)) {
-                    done[l] = false;
-                    st[l] = {jl * subbits, 0, 0};
-                    uint32_t n = zj_decode_span<false>(stream, lut.data(), canon, sel, st[l], send(jl), nullptr);
-                    sinfo[jl] = zj_pack_info(st[l], (jl + 1) * subbits, n);
+                uint32_t jl = ch * 64 + l;
+                done[l] = !active(jl);
+                st[l] = {jl * subbits, 0, 0};
+                if (done[l]) continue;
+                for (uint32_t c = 0; c < NC; c++) {
+                    if (st[l].p >= send(jl)) break;
+                    uint32_t w = jl * NC + c;
+                    uint32_t n = window(st[l], w, send(jl));
+                    rec[zj_rec_index(jl, c, NC)] = zj_pack_info(st[l], (w + 1) * ZJ_WIN_BITS, n);
                 }
             }
             uint32_t rounds = 0;
@@ -86,21 +99,26 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
                 bool any = false;
                 bool act[64];
                 for (uint32_t l = 0; l < 64; l++) {
-                    act[l] = !done[l] && l + k2 < 64 && active(c * 64 + l + k2);
+                    act[l] = !done[l] && l + k2 < 64 && active(ch * 64 + l + k2);
                     if (!act[l]) done[l] = true;
                     any = any || act[l];
                 }
                 if (!any) break;
                 rounds++;
-                // reads and writes of one round touch distinct records, so lane order is free
+                // the walks of one round touch distinct subsequences, so lane order is free
                 for (uint32_t l = 0; l < 64; l++) {
                     if (!act[l]) continue;
-                    uint32_t q = c * 64 + l + k2;
-                    uint32_t n = zj_decode_span<false>(stream, lut.data(), canon, sel, st[l], send(q), nullptr);
-                    uint32_t nw = zj_pack_info(st[l], (q + 1) * subbits, n);
-                    uint32_t old = sinfo[q];
-                    sinfo[q] = nw;
-                    if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0) done[l] = true;
+                    uint32_t q = ch * 64 + l + k2;
+                    for (uint32_t c = 0; c < NC; c++) {
+                        if (st[l].p >= send(q)) break;
+                        uint32_t w = q * NC + c;
+                        uint32_t n = window(st[l], w, send(q));
+                        uint32_t nw = zj_pack_info(st[l], (w + 1) * ZJ_WIN_BITS, n);
+                        uint32_t &r = rec[zj_rec_index(q, c, NC)];
+                        uint32_t old = r;
+                        r = nw;
+                        if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0) { done[l] = true; break; }
+                    }
                 }
             }
             stats->rounds_max = std::max(stats->rounds_max, rounds);
@@ -108,45 +126,63 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
             stats->nchunks++;
         }
         // k1b: one pass of boundary fix-up (lane order = any; emulate ascending)
-        for (uint32_t c = 1; c < nchunk; c++) {
-            uint32_t jl0 = c * 64;
-            if (!active(jl0)) continue;
-            ZjState st = zj_unpack_state(sinfo[jl0 - 1], jl0 * subbits);
+        for (uint32_t ch = 1; ch < nchunk; ch++) {
+            uint32_t q0 = ch * 64;
+            if (!active(q0)) continue;
+            ZjState st = zj_unpack_state(rec[zj_rec_index(q0 - 1, NC - 1, NC)], q0 * subbits);
             uint32_t steps = 0;
-            for (uint32_t t = 0; t < 64; t++) {
-                uint32_t q = jl0 + t;
-                if (!active(q)) break;
-                steps++;
-                uint32_t n = zj_decode_span<false>(stream, lut.data(), canon, sel, st, send(q), nullptr);
-                uint32_t nw = zj_pack_info(st, (q + 1) * subbits, n);
-                uint32_t old = sinfo[q];
-                sinfo[q] = nw;
-                if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0) break;
-                if (t == 63) stats->need_more = 1;
+            bool synced = false;
+            for (uint32_t t = 0; t < 64 && !synced; t++) {
+                uint32_t q = q0 + t;
+                if (!active(q)) { synced = true; break; }
+                for (uint32_t c = 0; c < NC; c++) {
+                    if (st.p >= send(q)) break;
+                    steps++;
+                    uint32_t w = q * NC + c;
+                    uint32_t n = window(st, w, send(q));
+                    uint32_t nw = zj_pack_info(st, (w + 1) * ZJ_WIN_BITS, n);
+                    uint32_t &r = rec[zj_rec_index(q, c, NC)];
+                    uint32_t old = r;
+                    r = nw;
+                    if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0) { synced = true; break; }
+                }
             }
+            if (!synced) stats->need_more = 1;
             stats->fix_steps_max = std::max(stats->fix_steps_max, steps);
             stats->fix_steps_sum += steps;
         }
         // k1s
         uint32_t carry = 0;
-        for (uint32_t q = 0; q < nsub; q++) { base[q] = carry; carry += sinfo[q] >> 16; }
+        for (uint32_t q = 0; q < nsub; q++) {
+            base[q] = carry;
+            for (uint32_t c = 0; c < NC; c++) carry += rec[zj_rec_index(q, c, NC)] >> 16;
+        }
         const uint32_t found = std::min(carry, nblocks);
         // k1i
         std::vector<uint32_t> blockpos(nblocks + 1, 0);
-        std::vector<int16_t> dcdiff(nblocks + 1, 0), dcabs(nblocks + 1, 0);
+        std::vector<int16_t> dcabs(nblocks + 1, 0);
         for (uint32_t q = 0; q < nsub; q++) {
             if (!active(q)) continue;
-            ZjState st = {0, 0, 0};
-            if (q > 0) st = zj_unpack_state(sinfo[q - 1], q * subbits);
-            ZjIndexOut io = {blockpos.data(), dcdiff.data(), base[q], nblocks};
-            uint32_t n = zj_decode_span<true>(stream, lut.data(), canon, sel, st, send(q), &io);
-            if (zj_pack_info(st, (q + 1) * subbits, n) != sinfo[q]) stats->verify_fail = 1;
+            ZjState st = {q * subbits, 0, 0};
+            if (q > 0) st = zj_unpack_state(rec[zj_rec_index(q - 1, NC - 1, NC)], q * subbits);
+            ZjIndexOut io = {blockpos.data(), base[q], nblocks};
+            for (uint32_t c = 0; c < NC; c++) {
+                if (st.p >= send(q)) break;
+                uint32_t w = q * NC + c, wend = (w + 1) * ZJ_WIN_BITS;
+                ZjBits bits;
+                bits.init(stream, st.p);
+                uint32_t n = zj_decode_run<ZjBits, true>(bits, lut.data(), canon, selw, bpm, st, wend < send(q) ? wend : send(q), &io);
+                if (zj_pack_info(st, wend, n) != rec[zj_rec_index(q, c, NC)]) stats->verify_fail = 1;
+            }
         }
         // k1d
         uint32_t run[3] = {0, 0, 0};
         for (uint32_t g = 0; g < nblocks; g++) {
             uint32_t c = (compsel >> (2 * (g % bpm))) & 3;
-            if (g < found) run[c] += (uint32_t)(int32_t)dcdiff[g];
+            if (g < found) {
+                uint32_t t = (sel.dcsel >> (g % bpm)) & 1;
+                run[c] += (uint32_t)zj_dc_diff(stream, &lut[t * ZJ_TBL_ENTRIES], &canon[t], blockpos[g]);
+            }
             dcabs[g] = (int16_t)run[c];
         }
         // k1w

@@ -142,7 +142,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
 
     b->imgs.resize(n);
     b->unsupported.assign(n, 0);
-    std::vector<uint32_t> chunk_seg, blk256_img;
+    std::vector<uint32_t> chunk_seg, blk256_img, k1w_img;
     std::vector<uint32_t> k2_grp[4], k2_img[4]; // stage-2 workgroups per sampling layout
     std::vector<uint16_t> luts;
     std::vector<ZjCanon> canons;
@@ -258,6 +258,11 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
         const uint32_t nb_pad = (uint32_t)align_up(d.nblocks, 256);
         for (uint32_t g = 0; g < nb_pad / 256; g++) blk256_img.push_back((uint32_t)i);
         nblk_total += nb_pad;
+        {
+            const uint32_t per_wg = 4u * (d.hs * d.vs == 1 ? 64u : 32u); // MCUs per write-pass workgroup
+            d.first_k1w = (uint32_t)k1w_img.size();
+            for (uint64_t m = 0; m < nmcu; m += per_wg) k1w_img.push_back((uint32_t)i);
+        }
         const uint32_t T = 96 / d.bpm;
         d.strips_x = (d.mcux + T - 1) / T;
         const uint32_t ns = (d.strips_x * d.mcuy + ZJ_K2_NS - 1) / ZJ_K2_NS; // workgroups of stage 2
@@ -277,6 +282,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.segs = dev_upload(b, b->segs);
     P.chunk_seg = dev_upload(b, chunk_seg);
     P.blk256_img = dev_upload(b, blk256_img);
+    P.k1w_img = dev_upload(b, k1w_img);
     std::vector<uint32_t> strip_grp_all, strip_img_all;
     for (int c = 0; c < 4; c++) {
         b->L.k2_first[c] = (uint32_t)strip_grp_all.size();
@@ -308,7 +314,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.nchunks = (uint32_t)chunk_seg.size();
     P.subbits = subbits;
     P.nc = subbits / ZJ_WIN_BITS;
-    ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.strip_img && P.strip_img_img && P.luts && P.canons && P.qts && raw && P.ust &&
+    ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.canons && P.qts && raw && P.ust &&
          P.seg_payload_bits && P.seg_found && P.winfo && P.base && P.blockpos && P.dcabs && P.qcoef && P.status &&
          P.flags && b->d_rgb && b->d_stride;
     if (ok) ok = hip_ok(ctx, hipHostMalloc((void **)&b->h_rgb, (n ? n : 1) * sizeof(uint8_t *), hipHostMallocDefault), "hipHostMalloc") &&
@@ -328,6 +334,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     b->L.nseg = (uint32_t)b->segs.size();
     b->L.nchunks = P.nchunks;
     b->L.nblk256 = (uint32_t)blk256_img.size();
+    b->L.nk1w = (uint32_t)k1w_img.size();
     b->L.nstrips = (uint32_t)strip_grp_all.size();
     b->L.fix_iters = 1;
     return b;

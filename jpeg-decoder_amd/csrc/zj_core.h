@@ -62,7 +62,7 @@ struct ZjImgDev {
     uint32_t first_strip;   // first global strip index of stage 2
     uint32_t strips_x;      // strips per MCU row
     uint32_t flags;         // bit 0: supported
-    uint32_t pad0;
+    uint32_t first_k1w;     // first workgroup of the write pass
 };
 
 struct ZjSegDev {

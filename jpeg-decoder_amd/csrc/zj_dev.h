@@ -35,6 +35,7 @@ struct ZjParams {
     const ZjCanon *canons;      // [table set][4]
     const uint16_t *qts;        // quantisation tables widened to 16 bits, 64 entries each, zig-zag order
     const uint32_t *blk256_img; // [block / 256] image
+    const uint32_t *k1w_img;    // [write-pass workgroup] image
     const uint32_t *strip_img;     // [stage-2 workgroup] index of its strip group inside its image
     const uint32_t *strip_img_img; // [stage-2 workgroup] image
     uint32_t *status;           // [image]
@@ -49,7 +50,7 @@ struct ZjParams {
 #define ZJ_K2_NS 4 // strips per workgroup of the IDCT/colour kernel
 
 struct ZjLaunch {
-    uint32_t nseg, nchunks, nblk256, nstrips;
+    uint32_t nseg, nchunks, nblk256, nstrips, nk1w;
     uint32_t k2_first[4], k2_count[4]; // stage-2 workgroups per sampling layout (2x2, 1x1, 2x1, 1x2)
     int fix_iters;
 };

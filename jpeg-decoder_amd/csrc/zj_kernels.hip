@@ -58,6 +58,16 @@ __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t *wsum, 
     return inc + off;
 }
 
+// Order LDS accesses of the lanes of one wavefront between two phases (the wavefront runs in lock
+// step, so no barrier is needed, only that neither compiler nor hardware reorders around this point).
+__device__ __forceinline__ void zj_wave_lds_sync()
+{
+    // LDS operations of a wavefront are executed in issue order; the wait drains them, the "memory"
+    // clobber keeps the compiler from moving LDS accesses across, and global loads stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ bool sub_active(const ZjSegDev &sg, uint32_t q, uint32_t subbits, uint32_t payload_bits)
 {
     return q < sg.nsub && (uint64_t)q * subbits < (uint64_t)payload_bits;
@@ -485,56 +495,76 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan(ZjParams P)
 }
 
 // ---------------------------------------------------------------------------------- k1w: write
-// 256 threads = 256 consecutive blocks of one image.  Each lane decodes its block into a private
-// 132-byte row of an LDS tile (row stride of 33 words keeps lanes on distinct banks while they
-// write the same zig-zag index), then the wavefront stores its 64 rows as 8 KiB of contiguous,
-// fully coalesced 16-byte pieces.
+// One lane per block.  A wavefront owns a run of MCUs and works through it in rounds of 64 blocks of
+// one kind -- all luma blocks first, then all chroma blocks -- because luma blocks carry several
+// times the symbols of chroma blocks and a round lasts as long as its longest block.  Each lane
+// decodes its block into a private 132-byte row of an LDS tile (a row pitch of 33 words keeps lanes
+// on distinct banks while they write the same zig-zag index); then the wavefront stores the 64 rows,
+// eight lanes per block, one full 128-byte line per block.
+// MCUs per wavefront: 64 for 4:4:4 (1 luma + 2 chroma rounds), 32 otherwise.
 __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
     __shared__ uint32_t tile[4][64 * 33];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t g0 = blockIdx.x * 256u;
-    const uint32_t ii = P.blk256_img[blockIdx.x];
+    const uint32_t ii = P.k1w_img[blockIdx.x];
     const ZjImgDev &im = P.imgs[ii];
     load_lut_to_lds(lut, P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
-    uint32_t *row32 = &tile[wave][lane * 33u];
-#pragma unroll
-    for (int i = 0; i < 33; i++) row32[i] = 0;
     __syncthreads();
 
-    const uint32_t g = g0 + threadIdx.x;
-    const uint32_t gl = g - im.first_block;
-    if (gl < im.nblocks) {
-        const uint32_t segi = im.ri_blocks ? gl / im.ri_blocks : 0u;
-        const uint32_t seg = im.first_seg + segi;
-        const uint32_t gs = gl - segi * im.ri_blocks;
-        const uint64_t out_off = P.segs[seg].out_off;
-        const uint32_t found = P.seg_found[seg];
-        uint32_t st;
-        if (gs < found) {
-            const uint32_t k = gs % im.bpm;
-            const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + out_off);
-            uint32_t pend;
-            st = zj_decode_block(stream, lut, canon, (im.dcsel >> k) & 1u, (im.acsel >> k) & 1u, P.blockpos[g],
-                                 P.dcabs[g], reinterpret_cast<int16_t *>(row32), &pend);
-            if (pend > P.seg_payload_bits[seg]) st |= 4u; // ZJ_ST_TRUNCATED
-        } else {
-            st = 4u;
-        }
-        if (st) atomicOr(&P.status[ii], st);
-    }
-    __syncthreads();
-    int16_t *dst = P.qcoef + ((size_t)g0 + wave * 64u) * 64u;
+    const uint32_t nl = im.hs * im.vs, bpm = im.bpm;
+    const uint32_t M = nl == 1u ? 64u : 32u;                       // MCUs per wavefront
+    const uint32_t m0 = ((blockIdx.x - im.first_k1w) * 4u + wave) * M; // first MCU of this wavefront
+    const uint32_t nmcu = im.nblocks / bpm;
+    if (m0 >= nmcu) return; // wave-uniform
+    const uint32_t rounds_l = M * nl / 64u, rounds = rounds_l + M * 2u / 64u;
+    uint32_t *row32 = &tile[wave][lane * 33u];
+    uint32_t status = 0;
+    for (uint32_t r = 0; r < rounds; r++) {
 #pragma unroll
-    for (uint32_t it = 0; it < 8u; it++) {
-        const uint32_t q = it * 64u + lane;
-        const uint32_t blk = q >> 3, part = q & 7u;
-        const uint32_t *src = &tile[wave][blk * 33u + part * 4u];
-        uint4 v = make_uint4(src[0], src[1], src[2], src[3]);
-        *reinterpret_cast<uint4 *>(dst + (size_t)q * 8u) = v;
+        for (int i = 0; i < 33; i++) row32[i] = 0;
+        // block of this lane in this round
+        const bool luma = r < rounds_l;
+        const uint32_t qi = (luma ? r : r - rounds_l) * 64u + lane;
+        const uint32_t per = luma ? nl : 2u;
+        const uint32_t mcu = m0 + qi / per;
+        const uint32_t kb = (luma ? 0u : nl) + qi % per;
+        const uint32_t gl = mcu * bpm + kb; // block index inside the image
+        if (mcu < nmcu) {
+            const uint32_t g = im.first_block + gl;
+            const uint32_t segi = im.ri_blocks ? gl / im.ri_blocks : 0u;
+            const uint32_t seg = im.first_seg + segi;
+            const uint32_t gs = gl - segi * im.ri_blocks;
+            uint32_t st;
+            if (gs < P.seg_found[seg]) {
+                const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[seg].out_off);
+                uint32_t pend;
+                st = zj_decode_block(stream, lut, canon, (im.dcsel >> kb) & 1u, (im.acsel >> kb) & 1u, P.blockpos[g],
+                                     P.dcabs[g], reinterpret_cast<int16_t *>(row32), &pend);
+                if (pend > P.seg_payload_bits[seg]) st |= 4u; // ZJ_ST_TRUNCATED
+            } else {
+                st = 4u;
+            }
+            status |= st;
+        }
+        zj_wave_lds_sync();
+        // store: piece q = (row q / 8, sixteen bytes q % 8); the row's block is recomputed from its lane
+#pragma unroll
+        for (uint32_t it = 0; it < 8u; it++) {
+            const uint32_t q = it * 64u + lane;
+            const uint32_t rl = q >> 3, part = q & 7u;
+            const uint32_t qj = (luma ? r : r - rounds_l) * 64u + rl;
+            const uint32_t mj = m0 + qj / per;
+            if (mj < nmcu) {
+                const uint32_t gj = im.first_block + mj * bpm + (luma ? 0u : nl) + qj % per;
+                const uint32_t *src = &tile[wave][rl * 33u + part * 4u];
+                *reinterpret_cast<uint4 *>(P.qcoef + (size_t)gj * 64u + part * 8u) = make_uint4(src[0], src[1], src[2], src[3]);
+            }
+        }
+        zj_wave_lds_sync();
     }
+    if (status) atomicOr(&P.status[ii], status);
 }
 
 // ---------------------------------------------------------------------------------- k2: IDCT + colour
@@ -597,16 +627,6 @@ typedef unsigned short zj_u16x2 __attribute__((ext_vector_type(2)));
 #define ZJ_K2_WBLOCKS 24  // of which each wavefront takes a quarter and works on it without workgroup barriers
 #define ZJ_K2_BSTRIDE 72  // floats per block in LDS: 64 + 8 keeps the column pass conflict-free
 // ZJ_K2_NS (zj_dev.h) strips per workgroup; the next strip's coefficients are fetched while this one computes
-
-// Order LDS accesses of the lanes of one wavefront between two phases (the wavefront runs in lock
-// step, so no barrier is needed, only that neither compiler nor hardware reorders around this point).
-__device__ __forceinline__ void zj_wave_lds_sync()
-{
-    // LDS operations of a wavefront are executed in issue order; the wait drains them, the "memory"
-    // clobber keeps the compiler from moving LDS accesses across, and global loads stay in flight
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
 
 template <int HS, int VS>
 __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im, uint32_t ii, uint32_t strip0,
@@ -851,7 +871,7 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     hipLaunchKernelGGL(zj_k1c_dcdiff, dim3(L.nblk256), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.nseg), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
-    hipLaunchKernelGGL(zj_k1w_write, dim3(L.nblk256), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
 }
 
@@ -866,7 +886,7 @@ extern "C" void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipS
     hipLaunchKernelGGL(zj_k1i_index, dim3(L.nchunks / 4), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1c_dcdiff, dim3(L.nblk256), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.nseg), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(zj_k1w_write, dim3(L.nblk256), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
 }
 
 extern "C" void zj_launch_stage2(const ZjParams &P, const ZjLaunch &L, hipStream_t st, hipEvent_t *ev)

@@ -292,7 +292,11 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     }
     P.strip_img = dev_upload(b, strip_grp_all);
     P.strip_img_img = dev_upload(b, strip_img_all);
+    std::vector<uint32_t> wluts(luts.size());
+    for (size_t t = 0; t < luts.size() / ZJ_TBL_ENTRIES; t++)
+        zj_build_walk_table(&luts[t * ZJ_TBL_ENTRIES], (t & 3u) < 2u, &wluts[t * ZJ_TBL_ENTRIES]);
     P.luts = dev_upload(b, luts);
+    P.wluts = dev_upload(b, wluts);
     P.canons = dev_upload(b, canons);
     P.qts = dev_upload(b, qts);
     uint8_t *raw = dev_alloc<uint8_t>(b, raw_total + 1040, false);
@@ -314,7 +318,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.nchunks = (uint32_t)chunk_seg.size();
     P.subbits = subbits;
     P.nc = subbits / ZJ_WIN_BITS;
-    ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.canons && P.qts && raw && P.ust &&
+    ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.wluts && P.canons && P.qts && raw && P.ust &&
          P.seg_payload_bits && P.seg_found && P.winfo && P.base && P.blockpos && P.dcabs && P.qcoef && P.status &&
          P.flags && b->d_rgb && b->d_stride;
     if (ok) ok = hip_ok(ctx, hipHostMalloc((void **)&b->h_rgb, (n ? n : 1) * sizeof(uint8_t *), hipHostMallocDefault), "hipHostMalloc") &&

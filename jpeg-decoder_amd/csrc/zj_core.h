@@ -33,6 +33,12 @@
 #define ZJ_L2_SIZE 256
 #define ZJ_TBL_ENTRIES (ZJ_L1_SIZE + ZJ_L2_SIZE)
 #define ZJ_SET_ENTRIES (4 * ZJ_TBL_ENTRIES)
+// The walks that only need to follow the decoder state (sync, fix, index) use a second form of the same
+// tables with 32-bit entries that hold the state transition ready-made ("walk entries"):
+//   entry, bit 31 clear:  [5:0] bits to consume (code + value bits, 1..32), [12:6] zig-zag advance
+//                         (DC symbol: 1; AC symbol: run + 1; EOB: 64, which ends the block; a bit
+//                         pattern that is no code: consume 1 bit, advance as an EOB / a DC symbol)
+//   entry, bit 31 set  :  first level only: [30:28] nb, [8:0] sub-table offset, as above
 
 // Canonical description of one table, used by the rare fallback path only.
 struct ZjCanon {
@@ -259,6 +265,28 @@ ZJ_HD_NOINLINE uint32_t zj_canon_lookup(const ZjCanon *c, uint32_t top32)
     return 0;
 }
 
+// Walk entry of a (length, symbol) entry; `isdc` says which kind of table it came from.
+ZJ_HD uint32_t zj_walk_entry(uint32_t e, bool isdc)
+{
+    const uint32_t len = (e >> 8) & 31u, sym = e & 255u;
+    if (len == 0) return 1u | ((isdc ? 1u : 64u) << 6);
+    const uint32_t sbits = isdc ? (sym > 16u ? 16u : sym) : (sym & 15u);
+    const uint32_t zadv = isdc ? 1u : (sym == 0 ? 64u : (sym >> 4) + 1u);
+    return (len + sbits) | (zadv << 6);
+}
+
+// wtbl: one table of walk entries (ZJ_TBL_ENTRIES entries).
+ZJ_HD uint32_t zj_lookup_walk(const uint32_t *wtbl, const ZjCanon *canon, uint32_t top32, bool isdc)
+{
+    uint32_t e = wtbl[top32 >> (32 - ZJ_L1_BITS)];
+    if (e & 0x80000000u) {
+        const uint32_t nb = (e >> 28) & 7u;
+        if (nb == 0) return zj_walk_entry(zj_canon_lookup(canon, top32), isdc);
+        e = wtbl[ZJ_L1_SIZE + (e & 0x1FFu) + ((top32 >> (32 - ZJ_L1_BITS - nb)) & ((1u << nb) - 1u))];
+    }
+    return e;
+}
+
 // tbl: one table (ZJ_TBL_ENTRIES entries).  Returns [12:8] length, [7:0] symbol; length 0 = invalid.
 ZJ_HD uint32_t zj_lookup(const uint16_t *tbl, const ZjCanon *canon, uint32_t top32)
 {
@@ -294,6 +322,16 @@ ZJ_HD int32_t zj_dc_diff(const uint32_t *stream, const uint16_t *dctbl, const Zj
     return zj_extend(s, v);
 }
 
+// The value bits behind an AC code and their EXTEND in one go, for nbits 0..15 (AC sizes): `x` is the
+// 32-bit window shifted left past the code.  Equal to zj_extend(nbits, x >> (32 - nbits)); the form
+// avoids the compare and the special case for nbits == 0.
+ZJ_HD int32_t zj_value_ac(uint32_t x, uint32_t nbits)
+{
+    const uint32_t v = (x >> 1) >> (31u - nbits);
+    const uint32_t neg = (uint32_t)((int32_t)(~x) >> 31); // all ones when the leading value bit is 0
+    return (int32_t)(int16_t)(v - (neg & ((1u << nbits) - 1u)));
+}
+
 struct ZjSel { // table selectors of the image a lane works on
     uint32_t bpm, dcsel, acsel;
 };
@@ -321,8 +359,9 @@ struct ZjIndexOut {
 // as a state machine over (bit position, block in MCU, zig-zag index).  Returns the number of
 // blocks that began.  With INDEX it also records where each block begins and its DC difference.
 // The walk itself, on a reader that is already positioned at st.p: symbols that start before `stop`.
+// `wlut` is a table set of walk entries.
 template <class BITS, bool INDEX>
-ZJ_HD uint32_t zj_decode_run(BITS &bits, const uint16_t *lut, const ZjCanon *canon, uint32_t selw, uint32_t bpm,
+ZJ_HD uint32_t zj_decode_run(BITS &bits, const uint32_t *wlut, const ZjCanon *canon, uint32_t selw, uint32_t bpm,
                              ZjState &st, uint32_t stop, ZjIndexOut *io)
 {
     uint32_t nblk = 0;
@@ -333,12 +372,8 @@ ZJ_HD uint32_t zj_decode_run(BITS &bits, const uint16_t *lut, const ZjCanon *can
         const uint32_t top = bits.top32();
         const bool isdc = (z == 0);
         const uint32_t t = (selw >> (2u * b + (isdc ? 0u : 16u))) & 3u;
-        const uint32_t e = zj_lookup(lut + t * ZJ_TBL_ENTRIES, canon ? canon + t : nullptr, top);
-        const uint32_t len = (e >> 8) & 31u, sym = e & 255u;
-        uint32_t s = isdc ? sym : (sym & 15u);
-        s = s > 16u ? 16u : s;
-        uint32_t tot = len + s; // a DC symbol and its bits, or an AC symbol and its bits: at most 32
-        tot = tot ? tot : 1u;   // no such code: keep moving, the write pass reports it
+        const uint32_t e = zj_lookup_walk(wlut + t * ZJ_TBL_ENTRIES, canon ? canon + t : nullptr, top, t < 2u);
+        const uint32_t tot = e & 63u;
         if (INDEX) {
             if (isdc) {
                 if (io->g < io->glimit) io->blockpos[io->g] = p;
@@ -346,11 +381,9 @@ ZJ_HD uint32_t zj_decode_run(BITS &bits, const uint16_t *lut, const ZjCanon *can
             }
         }
         nblk += isdc ? 1u : 0u;
-        // AC: EOB ends the block, otherwise skip `run` zeros and place one coefficient
-        const uint32_t zac = (sym == 0u) ? 64u : z + (sym >> 4) + 1u;
-        const uint32_t zn = isdc ? 1u : zac;
-        const bool endblk = zn >= 64u;
-        z = endblk ? 0u : zn;
+        const uint32_t z2 = z + ((e >> 6) & 127u);
+        const bool endblk = z2 >= 64u;
+        z = endblk ? 0u : z2;
         b += endblk ? 1u : 0u;
         b = (b >= bpm) ? 0u : b;
         bits.skip(tot);
@@ -361,18 +394,20 @@ ZJ_HD uint32_t zj_decode_run(BITS &bits, const uint16_t *lut, const ZjCanon *can
 }
 
 template <bool INDEX>
-ZJ_HD uint32_t zj_decode_span(const uint32_t *stream, const uint16_t *lut, const ZjCanon *canon, const ZjSel &sel,
+ZJ_HD uint32_t zj_decode_span(const uint32_t *stream, const uint32_t *wlut, const ZjCanon *canon, const ZjSel &sel,
                               ZjState &st, uint32_t end, ZjIndexOut *io)
 {
     if (st.p >= end) return 0;
     ZjBits bits;
     bits.init(stream, st.p);
-    return zj_decode_run<ZjBits, INDEX>(bits, lut, canon, zj_selword(sel), sel.bpm, st, end, io);
+    return zj_decode_run<ZjBits, INDEX>(bits, wlut, canon, zj_selword(sel), sel.bpm, st, end, io);
 }
 
-// Decode one block that begins at bit `p0` into row[0..63] (zig-zag order, already zeroed).
-// The DC value comes from the prefix scan; only its bits are skipped here.  Returns status bits and
-// the bit position behind the block.
+// Decode one block that begins at bit `p0` into row[0..63] (zig-zag order, already zeroed; row[64] and
+// row[65] are scratch that absorbs the store of the symbol that ends the block).  The DC value comes
+// from the prefix scan; only its bits are skipped here.  The AC loop is written with selects instead
+// of branches: the lanes of a wavefront are at different points of different blocks.  Returns status
+// bits and the bit position behind the block.
 ZJ_HD uint32_t zj_decode_block(const uint32_t *stream, const uint16_t *lut, const ZjCanon *canon, uint32_t tdc,
                                uint32_t tac, uint32_t p0, int16_t dc, int16_t *row, uint32_t *pend)
 {
@@ -390,22 +425,23 @@ ZJ_HD uint32_t zj_decode_block(const uint32_t *stream, const uint16_t *lut, cons
     row[0] = dc;
     const uint16_t *ac = lut + (2u + tac) * ZJ_TBL_ENTRIES;
     const ZjCanon *cac = canon ? canon + 2u + tac : nullptr;
-    uint32_t z = 1;
-    while (z < 64u) {
-        uint32_t top = bits.top32();
-        uint32_t e = zj_lookup(ac, cac, top);
-        uint32_t len = (e >> 8) & 31u, sym = e & 255u;
-        if (len == 0) { status |= 1u; break; }
-        uint32_t s = sym & 15u;
-        p += len + s;
-        if (sym == 0) break; // EOB
-        z += sym >> 4;
-        if (z >= 64u) { status |= 2u; /* ZJ_ST_COEF_OVERFLOW */ break; }
-        uint32_t v = s ? ((top << len) >> (32 - s)) : 0u;
-        row[z] = (int16_t)zj_extend(s, v);
-        z++;
-        bits.skip(len + s);
+    uint32_t z = 1, e, z2;
+    for (;;) {
+        const uint32_t top = bits.top32();
+        e = zj_lookup(ac, cac, top);
+        const uint32_t len = (e >> 8) & 31u, s = e & 15u;
+        z2 = z + ((e >> 4) & 15u);                 // src/decoder.rs:225
+        const bool eob = (e & 255u) == 0;          // :212 (a pattern that is no code reads as 0 too)
+        const uint32_t at = z2 < 64u ? z2 : 64u;   // :228 would index out of bounds at 64 and above
+        row[eob ? 64u : at] = (int16_t)zj_value_ac(top << len, s);
+        const uint32_t adv = len + s;
+        p += adv;
+        if (eob || z2 >= 63u) break;               // :212, :232 (and the overflow case)
+        z = z2 + 1u;                               // :230
+        bits.skip(adv);
     }
+    if (((e >> 8) & 31u) == 0) status |= 1u;               // ZJ_ST_BAD_CODE
+    else if ((e & 255u) != 0 && z2 >= 64u) status |= 2u;   // ZJ_ST_COEF_OVERFLOW
     *pend = p;
     return status;
 }

@@ -79,11 +79,12 @@ __device__ __forceinline__ uint32_t sub_end(uint32_t q, uint32_t subbits, uint32
     return e < payload_bits ? (uint32_t)e : payload_bits;
 }
 
-__device__ __forceinline__ void load_lut_to_lds(uint16_t *lds, const uint16_t *src)
+template <class T>
+__device__ __forceinline__ void load_lut_to_lds(T *lds, const T *src)
 {
     const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
     uint4 *d4 = reinterpret_cast<uint4 *>(lds);
-    for (uint32_t i = threadIdx.x; i < ZJ_SET_ENTRIES * 2 / 16; i += blockDim.x) d4[i] = s4[i];
+    for (uint32_t i = threadIdx.x; i < ZJ_SET_ENTRIES * sizeof(T) / 16; i += blockDim.x) d4[i] = s4[i];
 }
 
 // ---------------------------------------------------------------------------------- windowed reader
@@ -147,7 +148,7 @@ __device__ __forceinline__ void zj_stage_window(const uint32_t *stream, uint32_t
 // whichever comes first.  The reader carries over from window to window; `primed` says whether it has
 // been positioned yet.  Returns the number of blocks that began.
 template <bool INDEX>
-__device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *stream, const uint16_t *lut,
+__device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *stream, const uint32_t *lut,
                                                    const ZjCanon *canon, uint32_t selw, uint32_t bpm, ZjState &st,
                                                    uint32_t win, uint32_t end, ZjIndexOut *io, uint32_t *col,
                                                    ZjBitsLds &bits, bool &primed)
@@ -252,7 +253,7 @@ extern __shared__ uint32_t zj_dyn_lds[];
 
 __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
+    __shared__ __attribute__((aligned(16))) uint32_t lut[ZJ_SET_ENTRIES];
     __shared__ uint32_t win[4][ZJ_WIN_SLOTS * 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t NC = P.nc, SB = P.subbits;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
     const uint32_t chunk = blockIdx.x * 4u + wave;
     const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
     const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
-    load_lut_to_lds(lut, P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
+    load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
     ZjSel sel = {im.bpm, im.dcsel, im.acsel};
     const uint32_t selw = zj_selword(sel);
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
     const uint32_t q0 = ch * 64u - sg.first_sub;
     if (!sub_active(sg, q0, SB, pay)) return;
     const ZjImgDev &im = P.imgs[sg.img];
-    const uint16_t *lut = P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES;
+    const uint32_t *lut = P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES;
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
     ZjSel sel = {im.bpm, im.dcsel, im.acsel};
     const uint32_t selw = zj_selword(sel);
@@ -383,14 +384,14 @@ __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
 // ---------------------------------------------------------------------------------- k1i: index
 __global__ __launch_bounds__(256) void zj_k1i_index(ZjParams P)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
+    __shared__ __attribute__((aligned(16))) uint32_t lut[ZJ_SET_ENTRIES];
     __shared__ uint32_t win[4][ZJ_WIN_SLOTS * 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t *col = &win[wave][lane];
     const uint32_t chunk = blockIdx.x * 4u + wave;
     const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
     const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
-    load_lut_to_lds(lut, P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
+    load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
     ZjSel sel = {im.bpm, im.dcsel, im.acsel};
     const uint32_t selw = zj_selword(sel);

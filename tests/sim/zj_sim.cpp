@@ -31,6 +31,8 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
         if (t4[t]) { if (!zj_build_table(t4[t], &lut[t * ZJ_TBL_ENTRIES], &canon[t])) return ZJ_E_FORMAT; }
         else memset(&canon[t], 0, sizeof(ZjCanon));
     }
+    std::vector<uint32_t> wlut(ZJ_SET_ENTRIES);
+    for (int t = 0; t < 4; t++) zj_build_walk_table(&lut[t * ZJ_TBL_ENTRIES], t < 2, &wlut[t * ZJ_TBL_ENTRIES]);
     ZjSel sel = {bpm, 0, 0};
     uint32_t compsel = 0;
     for (uint32_t k = 0; k < bpm; k++) {
@@ -76,7 +78,7 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
             if (st.p >= stop) return 0u;
             ZjBits bits;
             bits.init(stream, st.p);
-            return zj_decode_run<ZjBits, false>(bits, lut.data(), canon, selw, bpm, st, stop, nullptr);
+            return zj_decode_run<ZjBits, false>(bits, wlut.data(), canon, selw, bpm, st, stop, nullptr);
         };
         // k1a: per chunk, rounds in lock step, one record per window
         for (uint32_t ch = 0; ch < nchunk; ch++) {
@@ -171,7 +173,7 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
                 uint32_t w = q * NC + c, wend = (w + 1) * ZJ_WIN_BITS;
                 ZjBits bits;
                 bits.init(stream, st.p);
-                uint32_t n = zj_decode_run<ZjBits, true>(bits, lut.data(), canon, selw, bpm, st, wend < send(q) ? wend : send(q), &io);
+                uint32_t n = zj_decode_run<ZjBits, true>(bits, wlut.data(), canon, selw, bpm, st, wend < send(q) ? wend : send(q), &io);
                 if (zj_pack_info(st, wend, n) != rec[zj_rec_index(q, c, NC)]) stats->verify_fail = 1;
             }
         }
@@ -187,16 +189,26 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
         }
         // k1w
         for (uint32_t g = 0; g < nblocks; g++) {
-            int16_t *row = qc + (size_t)g * 64;
-            memset(row, 0, 128);
-            if (g >= found) { status |= ZJ_ST_TRUNCATED; continue; }
+            int16_t rowbuf[66];
+            memset(rowbuf, 0, sizeof rowbuf);
+            int16_t *row = rowbuf;
+            if (g >= found) { status |= ZJ_ST_TRUNCATED; memset(qc + (size_t)g * 64, 0, 128); continue; }
             uint32_t kb = g % bpm, pend;
             uint32_t s = zj_decode_block(stream, lut.data(), canon, (sel.dcsel >> kb) & 1, (sel.acsel >> kb) & 1, blockpos[g],
                                          dcabs[g], row, &pend);
             if (pend > pay) s |= ZJ_ST_TRUNCATED;
             status |= s;
+            memcpy(qc + (size_t)g * 64, rowbuf, 128);
         }
     }
     *status_out = status;
     return ZJ_OK;
+}
+
+// EXTEND of AC value bits, both forms, for the exhaustive equality test.
+extern "C" int zjsim_value_ac(uint32_t x, uint32_t nbits, int32_t *fast, int32_t *ref)
+{
+    *fast = zj_value_ac(x, nbits);
+    *ref = zj_extend(nbits, nbits ? x >> (32 - nbits) : 0);
+    return *fast == *ref;
 }

@@ -137,3 +137,21 @@ def test_no_gpu_is_a_loud_error():
     with pytest.raises(J.DecodeError) as e:
         J.Context(0)
     assert e.value.kind == "device"
+
+
+def test_ac_value_fast_form_equals_extend():
+    """The compare-free EXTEND used by the block writer equals the reference form (src/ec.rs sign_code) for
+    every AC size 0..15: all value patterns of the size, with random bits behind them."""
+    S = sim()
+    S.zjsim_value_ac.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    rng = np.random.default_rng(7)
+    f, r = C.c_int32(), C.c_int32()
+    for nbits in range(0, 16):
+        vals = range(1 << nbits) if nbits <= 10 else rng.integers(0, 1 << nbits, 2048)
+        for v in vals:
+            tail = int(rng.integers(0, 1 << (32 - nbits))) if nbits < 32 else 0
+            x = ((int(v) << (32 - nbits)) | tail) & 0xFFFFFFFF if nbits else tail
+            assert S.zjsim_value_ac(x, nbits, C.byref(f), C.byref(r)), (nbits, v, f.value, r.value)
+        # edge patterns
+        for x in (0, 0xFFFFFFFF, 0x80000000, 0x7FFFFFFF):
+            assert S.zjsim_value_ac(x, nbits, C.byref(f), C.byref(r)), (nbits, x)

@@ -122,7 +122,7 @@ def main():
         verified = bool(np.array_equal(got, ref.rgb) and np.array_equal(batch.coefficients(0), ref.qcoef))
 
         S, Cb, P, px = bc["scan"], bc["coef"], bc["rgb"], bc["pixels"]
-        alg = {"k0_unstuff": S, "k1a_sync": S, "k1b_fix": 0, "k1s_scan": 0, "k1i_index": S, "k1d_dcscan": 0,
+        alg = {"k0_unstuff": S, "k1a_sync": S, "k1b_fix": 0, "k1s_scan": 0, "k1p_positions": S, "k1d_dcscan": 0,
                "k1w_write": S + Cb, "k2_idct_rgb": Cb + P}
         dom = max((k for k in alg if k in ktimes), key=lambda k: ktimes[k])
         achieved = alg[dom] / (ktimes[dom] * 1e-3) / 1e9
@@ -143,7 +143,7 @@ def main():
             "dtype": "u8/i16 entropy decode, f32 IDCT+colour", "data": "synthetic",
             "config": {"workload": f"synthetic {a.width}x{a.height} {a.sampling} q{a.quality} baseline JPEG batch, "
                                    f"{a.images} images/GPU ({ndist} distinct seeds cycled), content class {a.content}",
-                       "images_per_gpu": a.images, "subseq_bits": a.subseq_bits or 1024, "timing": "device-resident"},
+                       "images_per_gpu": a.images, "subseq_bits": a.subseq_bits or "auto", "timing": "device-resident"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": round(ktimes[dom], 4)},

@@ -81,7 +81,7 @@ extern "C" void zj_destroy(zj_ctx *c)
 
 extern "C" const char *zj_last_error(zj_ctx *c) { return c ? c->err.c_str() : "no context"; }
 
-static const char *k_names[ZJ_NUM_KERNELS] = {"k0_unstuff", "k1a_sync", "k1b_fix",   "k1s_scan", "k1i_index",
+static const char *k_names[ZJ_NUM_KERNELS] = {"k0_unstuff", "k1a_sync", "k1b_fix",   "k1s_scan", "k1p_positions",
                                               "k1d_dcscan", "k1w_write", "k2_idct_rgb", "total"};
 extern "C" const char *zj_kernel_name(int k) { return (k >= 0 && k < ZJ_NUM_KERNELS) ? k_names[k] : ""; }
 
@@ -136,13 +136,24 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     memset(&b->P, 0, sizeof b->P);
     memset(&b->L, 0, sizeof b->L);
 
-    uint32_t subbits = flags & 0xFFFFu;
-    if (subbits == 0) subbits = 1024;
-    if (subbits < ZJ_WIN_BITS || subbits > 8192 || (subbits & (subbits - 1))) { ctx->err = "subsequence bits must be a power of two in 512..8192"; delete b; return nullptr; }
+    uint32_t subbits = flags & 0xFFFFFFu;
+    if (subbits == 0) {
+        // Enough subsequences to give every SIMD of the GPU a few wavefronts, and no more: the longer a
+        // subsequence, the smaller the share of the synchronisation rounds.
+        uint64_t bits = 0;
+        for (size_t i = 0; i < n; i++) bits += (uint64_t)images[i].scan_len * 8u;
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const uint64_t lanes = (uint64_t)cus * 16u * 64u;
+        subbits = 1024;
+        while (subbits < 65536u && (uint64_t)subbits * lanes < bits) subbits *= 2u;
+    }
+    if (subbits < ZJ_WIN_BITS || subbits > (1u << 20)) { ctx->err = "subsequence bits must be in 512..1048576"; delete b; return nullptr; }
 
     b->imgs.resize(n);
     b->unsupported.assign(n, 0);
-    std::vector<uint32_t> chunk_seg, blk256_img, k1w_img;
+    std::vector<uint32_t> chunk_seg, blk256_img, k1w_img, ptile_seg;
+    uint64_t nwin_total = 0;
     std::vector<uint32_t> k2_grp[4], k2_img[4]; // stage-2 workgroups per sampling layout
     std::vector<uint16_t> luts;
     std::vector<ZjCanon> canons;
@@ -241,9 +252,14 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             s.out_cap = (uint32_t)(align_up(rl, 16) + 96);
             ust_total += s.out_cap;
             s.img = (uint32_t)i;
-            s.nsub = (uint32_t)((rl * 8 + subbits - 1) / subbits);
+            zj_seg_layout((uint64_t)rl * 8u, subbits, &s.subbits, &s.nsub);
+            s.nc = s.subbits / ZJ_WIN_BITS;
             s.first_sub = d.first_sub + sub_in_img;
             const uint32_t nchunk = (s.nsub + 63) / 64;
+            s.first_win = (uint32_t)nwin_total;
+            nwin_total += (uint64_t)nchunk * 64u * s.nc;
+            s.first_ptile = (uint32_t)ptile_seg.size();
+            for (uint64_t w = 0; w < (uint64_t)s.nsub * s.nc; w += 256u) ptile_seg.push_back((uint32_t)b->segs.size());
             for (uint32_t c = 0; c < nchunk; c++) chunk_seg.push_back((uint32_t)b->segs.size());
             sub_in_img += nchunk * 64;
             const uint64_t m0 = ri ? k * ri : 0;
@@ -273,7 +289,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
         b->coef_bytes += (uint64_t)d.nblocks * 128;
         b->rgb_bytes += (uint64_t)d.w * d.h * 3;
         b->pixels += (uint64_t)d.w * d.h;
-        if (nsub_total > 0xF0000000ull || nblk_total > 0xF0000000ull) { ctx->err = "batch too large for 32-bit indices"; delete b; return nullptr; }
+        if (nsub_total > 0xF0000000ull || nblk_total > 0xF0000000ull || nwin_total > 0xF0000000ull) { ctx->err = "batch too large for 32-bit indices"; delete b; return nullptr; }
     }
 
     ZjParams &P = b->P;
@@ -283,6 +299,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.chunk_seg = dev_upload(b, chunk_seg);
     P.blk256_img = dev_upload(b, blk256_img);
     P.k1w_img = dev_upload(b, k1w_img);
+    P.ptile_seg = dev_upload(b, ptile_seg);
     std::vector<uint32_t> strip_grp_all, strip_img_all;
     for (int c = 0; c < 4; c++) {
         b->L.k2_first[c] = (uint32_t)strip_grp_all.size();
@@ -292,7 +309,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     }
     P.strip_img = dev_upload(b, strip_grp_all);
     P.strip_img_img = dev_upload(b, strip_img_all);
-    std::vector<uint32_t> wluts(luts.size());
+    std::vector<uint16_t> wluts(luts.size());
     for (size_t t = 0; t < luts.size() / ZJ_TBL_ENTRIES; t++)
         zj_build_walk_table(&luts[t * ZJ_TBL_ENTRIES], (t & 3u) < 2u, &wluts[t * ZJ_TBL_ENTRIES]);
     P.luts = dev_upload(b, luts);
@@ -304,8 +321,9 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.ust = dev_alloc<uint8_t>(b, ust_total + 1040, true);
     P.seg_payload_bits = dev_alloc<uint32_t>(b, b->segs.size(), true);
     P.seg_found = dev_alloc<uint32_t>(b, b->segs.size(), true);
-    P.winfo = dev_alloc<uint32_t>(b, nsub_total * (subbits / ZJ_WIN_BITS), true);
-    P.base = dev_alloc<uint32_t>(b, nsub_total, true);
+    P.winfo = dev_alloc<uint32_t>(b, nwin_total, true);
+    P.wbase = dev_alloc<uint32_t>(b, nwin_total, true);
+    P.bitmap = dev_alloc<uint8_t>(b, ust_total + 1040, true);
     P.blockpos = dev_alloc<uint32_t>(b, nblk_total, true);
     P.dcabs = dev_alloc<int16_t>(b, nblk_total, true);
     P.qcoef = dev_alloc<int16_t>(b, nblk_total * 64, false);
@@ -316,10 +334,8 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.rgb = b->d_rgb;
     P.rgb_stride = b->d_stride;
     P.nchunks = (uint32_t)chunk_seg.size();
-    P.subbits = subbits;
-    P.nc = subbits / ZJ_WIN_BITS;
     ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.wluts && P.canons && P.qts && raw && P.ust &&
-         P.seg_payload_bits && P.seg_found && P.winfo && P.base && P.blockpos && P.dcabs && P.qcoef && P.status &&
+         P.seg_payload_bits && P.seg_found && P.winfo && P.wbase && P.bitmap && P.ptile_seg && P.blockpos && P.dcabs && P.qcoef && P.status &&
          P.flags && b->d_rgb && b->d_stride;
     if (ok) ok = hip_ok(ctx, hipHostMalloc((void **)&b->h_rgb, (n ? n : 1) * sizeof(uint8_t *), hipHostMallocDefault), "hipHostMalloc") &&
                  hip_ok(ctx, hipHostMalloc((void **)&b->h_stride, (n ? n : 1) * sizeof(size_t), hipHostMallocDefault), "hipHostMalloc") &&
@@ -339,6 +355,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     b->L.nchunks = P.nchunks;
     b->L.nblk256 = (uint32_t)blk256_img.size();
     b->L.nk1w = (uint32_t)k1w_img.size();
+    b->L.nptiles = (uint32_t)ptile_seg.size();
     b->L.nstrips = (uint32_t)strip_grp_all.size();
     b->L.fix_iters = 1;
     return b;

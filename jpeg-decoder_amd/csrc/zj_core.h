@@ -34,11 +34,11 @@
 #define ZJ_TBL_ENTRIES (ZJ_L1_SIZE + ZJ_L2_SIZE)
 #define ZJ_SET_ENTRIES (4 * ZJ_TBL_ENTRIES)
 // The walks that only need to follow the decoder state (sync, fix, index) use a second form of the same
-// tables with 32-bit entries that hold the state transition ready-made ("walk entries"):
-//   entry, bit 31 clear:  [5:0] bits to consume (code + value bits, 1..32), [12:6] zig-zag advance
+// tables whose entries hold the state transition ready-made ("walk entries"):
+//   entry, bit 15 clear:  [5:0] bits to consume (code + value bits, 1..32), [12:6] zig-zag advance
 //                         (DC symbol: 1; AC symbol: run + 1; EOB: 64, which ends the block; a bit
 //                         pattern that is no code: consume 1 bit, advance as an EOB / a DC symbol)
-//   entry, bit 31 set  :  first level only: [30:28] nb, [8:0] sub-table offset, as above
+//   entry, bit 15 set  :  first level only: [14:12] nb, [8:0] sub-table offset, as above
 
 // Canonical description of one table, used by the rare fallback path only.
 struct ZjCanon {
@@ -80,6 +80,10 @@ struct ZjSegDev {
     uint32_t nsub;               // subsequences that can hold payload: ceil(raw bits / subsequence bits)
     uint32_t first_block;        // global block index of the segment's first block
     uint32_t nblocks;            // blocks coded in this segment
+    uint32_t subbits;            // bits per subsequence of this segment (multiple of ZJ_WIN_BITS)
+    uint32_t nc;                 // windows per subsequence = subbits / ZJ_WIN_BITS
+    uint32_t first_win;          // offset of the segment's window records / window bases (64 * nc per chunk)
+    uint32_t first_ptile;        // first workgroup of the position pass (256 windows each)
 };
 
 // Window records.  Every segment's unstuffed stream is cut into windows of ZJ_WIN_BITS bits; a
@@ -92,6 +96,11 @@ struct ZjSegDev {
 //   [31:16] blocks whose DC symbol starts inside this window
 // Records of one chunk (64 subsequences) are stored [window of the subsequence][lane], so that the
 // lanes of a wavefront touch consecutive words.
+//
+// Next to the records the walks leave a bitmap with one bit per stream bit (word w of the bitmap
+// belongs to stream word w; bit p & 31 of word p >> 5, counted from the least significant bit, is set
+// when a block's DC symbol starts at bit p).  A window's 16 bitmap words are always written together
+// by the lane that walked the window last, so a later, better-informed walk replaces them whole.
 #define ZJ_WIN_WORDS 16
 #define ZJ_WIN_BITS (ZJ_WIN_WORDS * 32)
 #define ZJ_INFO_STATE_MASK 0xFFFFu
@@ -99,6 +108,21 @@ struct ZjSegDev {
 // Index of the record of window c of subsequence q (both relative to the segment) inside the
 // segment's record area; nc = windows per subsequence.
 ZJ_HD uint32_t zj_rec_index(uint32_t q, uint32_t c, uint32_t nc) { return ((q >> 6) * nc + c) * 64u + (q & 63u); }
+
+// Subsequence size of a segment of `raw_bits` stuffed bits for a wanted size of `target` bits: the
+// segment is cut into a whole number of chunks (64 subsequences each) and the subsequence size is
+// what fills them evenly, rounded up to whole windows.  Every lane of every chunk then has work.
+ZJ_HD void zj_seg_layout(uint64_t raw_bits, uint32_t target, uint32_t *subbits, uint32_t *nsub)
+{
+    if (target < ZJ_WIN_BITS) target = ZJ_WIN_BITS;
+    uint64_t nchunk = (raw_bits + 32ull * target) / (64ull * target); // nearest whole number of chunks
+    if (nchunk == 0) nchunk = 1;
+    uint64_t sb = (raw_bits + 64ull * nchunk - 1) / (64ull * nchunk);
+    sb = (sb + ZJ_WIN_BITS - 1) / ZJ_WIN_BITS * ZJ_WIN_BITS;
+    if (sb == 0) sb = ZJ_WIN_BITS;
+    *subbits = (uint32_t)sb;
+    *nsub = (uint32_t)((raw_bits + sb - 1) / sb);
+}
 
 struct ZjState {
     uint32_t p; // bit position inside the segment's unstuffed stream
@@ -276,11 +300,11 @@ ZJ_HD uint32_t zj_walk_entry(uint32_t e, bool isdc)
 }
 
 // wtbl: one table of walk entries (ZJ_TBL_ENTRIES entries).
-ZJ_HD uint32_t zj_lookup_walk(const uint32_t *wtbl, const ZjCanon *canon, uint32_t top32, bool isdc)
+ZJ_HD uint32_t zj_lookup_walk(const uint16_t *wtbl, const ZjCanon *canon, uint32_t top32, bool isdc)
 {
     uint32_t e = wtbl[top32 >> (32 - ZJ_L1_BITS)];
-    if (e & 0x80000000u) {
-        const uint32_t nb = (e >> 28) & 7u;
+    if (e & 0x8000u) {
+        const uint32_t nb = (e >> 12) & 7u;
         if (nb == 0) return zj_walk_entry(zj_canon_lookup(canon, top32), isdc);
         e = wtbl[ZJ_L1_SIZE + (e & 0x1FFu) + ((top32 >> (32 - ZJ_L1_BITS - nb)) & ((1u << nb) - 1u))];
     }
@@ -348,23 +372,27 @@ ZJ_HD uint32_t zj_selword(const ZjSel &s)
     return w;
 }
 
-// What a span decode records besides the state.
-struct ZjIndexOut {
-    uint32_t *blockpos; // [segment block] bit position of the block's DC symbol
-    uint32_t g;         // next segment-relative block index
-    uint32_t glimit;    // blocks coded in the segment
+// What a walk leaves behind besides the state: block_start(p, f) is called for every symbol, with
+// f = 1 when the symbol at bit p is the DC symbol of a block and f = 0 otherwise (a call that always
+// happens keeps the loop free of branches on the decoder state).
+struct ZjNoEmit {
+    ZJ_HD void block_start(uint32_t, uint32_t) {}
+};
+struct ZjEmitWords { // bitmap words addressed directly (host side, and the one-lane fix pass)
+    uint32_t *words;
+    ZJ_HD void block_start(uint32_t p, uint32_t f)
+    {
+        if (f) words[p >> 5] |= 1u << (p & 31u);
+    }
 };
 
-// Walk the symbols that START inside [st.p, end) -- the serial loop of src/decoder.rs:194-235 seen
-// as a state machine over (bit position, block in MCU, zig-zag index).  Returns the number of
-// blocks that began.  With INDEX it also records where each block begins and its DC difference.
-// The walk itself, on a reader that is already positioned at st.p: symbols that start before `stop`.
-// `wlut` is a table set of walk entries.
-template <class BITS, bool INDEX>
-ZJ_HD uint32_t zj_decode_run(BITS &bits, const uint32_t *wlut, const ZjCanon *canon, uint32_t selw, uint32_t bpm,
-                             ZjState &st, uint32_t stop, ZjIndexOut *io)
+// Walk the symbols that START inside [st.p, stop) -- the serial loop of src/decoder.rs:194-235 seen
+// as a state machine over (bit position, block in MCU, zig-zag index) -- on a reader that is already
+// positioned at st.p.  `wlut` is a table set of walk entries.
+template <class BITS, class EMIT>
+ZJ_HD void zj_decode_run(BITS &bits, const uint16_t *wlut, const ZjCanon *canon, uint32_t selw, uint32_t bpm,
+                         ZjState &st, uint32_t stop, EMIT &em)
 {
-    uint32_t nblk = 0;
     uint32_t p = st.p, b = st.b, z = st.z;
     while (p < stop) {
         // everything below is select-based on purpose: lanes of a wavefront sit at different points of
@@ -374,13 +402,7 @@ ZJ_HD uint32_t zj_decode_run(BITS &bits, const uint32_t *wlut, const ZjCanon *ca
         const uint32_t t = (selw >> (2u * b + (isdc ? 0u : 16u))) & 3u;
         const uint32_t e = zj_lookup_walk(wlut + t * ZJ_TBL_ENTRIES, canon ? canon + t : nullptr, top, t < 2u);
         const uint32_t tot = e & 63u;
-        if (INDEX) {
-            if (isdc) {
-                if (io->g < io->glimit) io->blockpos[io->g] = p;
-                io->g++;
-            }
-        }
-        nblk += isdc ? 1u : 0u;
+        em.block_start(p, isdc ? 1u : 0u);
         const uint32_t z2 = z + ((e >> 6) & 127u);
         const bool endblk = z2 >= 64u;
         z = endblk ? 0u : z2;
@@ -390,17 +412,38 @@ ZJ_HD uint32_t zj_decode_run(BITS &bits, const uint32_t *wlut, const ZjCanon *ca
         p += tot;
     }
     st.p = p; st.b = b; st.z = z;
-    return nblk;
 }
 
-template <bool INDEX>
-ZJ_HD uint32_t zj_decode_span(const uint32_t *stream, const uint32_t *wlut, const ZjCanon *canon, const ZjSel &sel,
-                              ZjState &st, uint32_t end, ZjIndexOut *io)
+// Number of block starts marked in a window's 16 bitmap words.
+ZJ_HD uint32_t zj_popc32(uint32_t x)
 {
-    if (st.p >= end) return 0;
-    ZjBits bits;
-    bits.init(stream, st.p);
-    return zj_decode_run<ZjBits, INDEX>(bits, wlut, canon, zj_selword(sel), sel.bpm, st, end, io);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_popcount(x);
+#else
+    x = x - ((x >> 1) & 0x55555555u);
+    x = (x & 0x33333333u) + ((x >> 2) & 0x33333333u);
+    return (((x + (x >> 4)) & 0x0F0F0F0Fu) * 0x01010101u) >> 24;
+#endif
+}
+
+// One window of a walk on directly addressed memory: clears the window's bitmap words, walks the
+// symbols that start before `stop`, returns the window's record.  `win` is the window's index in
+// the segment; bitmap = the segment's bitmap (word 0 = stream word 0).
+ZJ_HD uint32_t zj_walk_window_direct(const uint32_t *stream, uint32_t *bitmap, const uint16_t *wlut,
+                                     const ZjCanon *canon, uint32_t selw, uint32_t bpm, ZjState &st, uint32_t win,
+                                     uint32_t stop)
+{
+    uint32_t *bw = bitmap + (uint64_t)win * ZJ_WIN_WORDS;
+    for (uint32_t i = 0; i < ZJ_WIN_WORDS; i++) bw[i] = 0;
+    if (st.p < stop) {
+        ZjBits bits;
+        bits.init(stream, st.p);
+        ZjEmitWords em = {bitmap};
+        zj_decode_run<ZjBits, ZjEmitWords>(bits, wlut, canon, selw, bpm, st, stop, em);
+    }
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < ZJ_WIN_WORDS; i++) n += zj_popc32(bw[i]);
+    return zj_pack_info(st, (win + 1u) * ZJ_WIN_BITS, n);
 }
 
 // Decode one block that begins at bit `p0` into row[0..63] (zig-zag order, already zeroed; row[64] and

@@ -11,7 +11,7 @@ enum {
     ZJ_K_SYNC,
     ZJ_K_FIX,
     ZJ_K_SCAN,
-    ZJ_K_INDEX,
+    ZJ_K_POSITIONS,
     ZJ_K_DCSCAN,
     ZJ_K_WRITE,
     ZJ_K_IDCT_RGB,
@@ -26,13 +26,15 @@ struct ZjParams {
     uint32_t *seg_payload_bits; // [seg] bits of unstuffed payload
     uint32_t *seg_found;        // [seg] blocks found in the payload
     const uint32_t *chunk_seg;  // [chunk of 64 subsequences] segment or ZJ_NONE
-    uint32_t *winfo;            // [chunk][window of the subsequence][lane] window records (zj_core.h)
-    uint32_t *base;             // [subsequence] blocks that begin earlier in the segment
+    uint32_t *winfo;            // per segment: [chunk][window of the subsequence][lane] window records (zj_core.h)
+    uint32_t *wbase;            // per segment: [window in stream order] blocks that begin earlier in the segment
+    uint8_t *bitmap;            // block-start bitmap, laid out like `ust` (one bit per stream bit)
+    const uint32_t *ptile_seg;  // [position-pass workgroup] segment
     uint32_t *blockpos;         // [block] bit position of the block in its segment's stream
     int16_t *dcabs;             // [block] DC value after prediction
     int16_t *qcoef;             // [block][64] zig-zag, quantised: the stage seam
     const uint16_t *luts;       // [table set][ZJ_SET_ENTRIES]
-    const uint32_t *wluts;      // the same sets as walk entries
+    const uint16_t *wluts;      // the same sets as walk entries
     const ZjCanon *canons;      // [table set][4]
     const uint16_t *qts;        // quantisation tables widened to 16 bits, 64 entries each, zig-zag order
     const uint32_t *blk256_img; // [block / 256] image
@@ -44,14 +46,12 @@ struct ZjParams {
     uint8_t *const *rgb;        // [image] device pointers
     const size_t *rgb_stride;   // [image]
     uint32_t nchunks;
-    uint32_t subbits;           // bits per subsequence
-    uint32_t nc;                // windows per subsequence = subbits / ZJ_WIN_BITS
 };
 
 #define ZJ_K2_NS 4 // strips per workgroup of the IDCT/colour kernel
 
 struct ZjLaunch {
-    uint32_t nseg, nchunks, nblk256, nstrips, nk1w;
+    uint32_t nseg, nchunks, nblk256, nstrips, nk1w, nptiles;
     uint32_t k2_first[4], k2_count[4]; // stage-2 workgroups per sampling layout (2x2, 1x1, 2x1, 1x2)
     int fix_iters;
 };

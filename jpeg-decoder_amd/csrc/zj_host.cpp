@@ -297,11 +297,11 @@ bool zj_build_table(const zj_huff *h, uint16_t *tbl, ZjCanon *canon)
 
 // The same table in walk-entry form (zj_core.h): long first-level entries keep their sub-table
 // reference, every other entry turns into (bits to consume, zig-zag advance).
-void zj_build_walk_table(const uint16_t *tbl, bool isdc, uint32_t *wtbl)
+void zj_build_walk_table(const uint16_t *tbl, bool isdc, uint16_t *wtbl)
 {
     for (uint32_t i = 0; i < ZJ_TBL_ENTRIES; i++) {
         const uint32_t e = tbl[i];
-        if (i < ZJ_L1_SIZE && (e & 0x8000u)) wtbl[i] = 0x80000000u | (((e >> 12) & 7u) << 28) | (e & 0x1FFu);
-        else wtbl[i] = zj_walk_entry(e, isdc);
+        if (i < ZJ_L1_SIZE && (e & 0x8000u)) wtbl[i] = (uint16_t)e;
+        else wtbl[i] = (uint16_t)zj_walk_entry(e, isdc);
     }
 }

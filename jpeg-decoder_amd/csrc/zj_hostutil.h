@@ -10,4 +10,4 @@ bool zj_image_supported(const zj_image *im);
 // Build one device lookup table (ZJ_TBL_ENTRIES entries) and its canonical description from a DHT
 // table.  Returns false if the table is not a prefix code.
 bool zj_build_table(const zj_huff *h, uint16_t *tbl, ZjCanon *canon);
-void zj_build_walk_table(const uint16_t *tbl, bool isdc, uint32_t *wtbl);
+void zj_build_walk_table(const uint16_t *tbl, bool isdc, uint16_t *wtbl);

@@ -97,21 +97,29 @@ __device__ __forceinline__ void load_lut_to_lds(T *lds, const T *src)
 // wavefront staging at the same moment, and the symbol loop refills from LDS.
 #define ZJ_WIN_SLOTS (ZJ_WIN_WORDS + 2)
 
+// The block-start bitmap of the window shares the column: a slot whose stream word has been taken
+// into the reader's buffer is cleared at that moment and from then on collects the bitmap word of the
+// same index (a block can only start at a bit the reader has already taken).
 struct ZjBitsLds {
-    const uint32_t *col; // this lane's column: word slot s at col[s * 64]
-    uint32_t widx;       // next stream word to take
-    uint32_t wbase;      // stream word held in slot 0
+    uint32_t *col;  // this lane's column: word slot s at col[s * 64]
+    uint32_t widx;  // next stream word to take
+    uint32_t wbase; // stream word held in slot 0
     uint64_t buf;
     int32_t cnt;
 
-    __device__ __forceinline__ uint32_t peek_word() const { return col[(widx - wbase) * 64u]; }
+    __device__ __forceinline__ uint32_t take_word()
+    {
+        uint32_t *slot = &col[(widx - wbase) * 64u];
+        const uint32_t w = *slot;
+        *slot = 0;
+        widx++;
+        return __builtin_bswap32(w);
+    }
     __device__ __forceinline__ void init(uint32_t bitpos)
     {
         widx = bitpos >> 5;
-        uint64_t w0 = __builtin_bswap32(peek_word());
-        widx++;
-        uint64_t w1 = __builtin_bswap32(peek_word());
-        widx++;
+        uint64_t w0 = take_word();
+        uint64_t w1 = take_word();
         const uint32_t sh = bitpos & 31u;
         buf = ((w0 << 32) | w1) << sh;
         cnt = 64 - (int32_t)sh;
@@ -122,21 +130,26 @@ struct ZjBitsLds {
         buf <<= n;
         cnt -= (int32_t)n;
         if (cnt <= 32) { // a branch, not a select: in the later rounds of the sync pass few lanes are live
-            const uint64_t w = __builtin_bswap32(peek_word());
-            widx++;
+            const uint64_t w = take_word();
             buf |= w << (32 - cnt);
             cnt += 32;
         }
     }
+    // a block's DC symbol starts at bit p (f = 1) or the symbol at p is something else (f = 0)
+    __device__ __forceinline__ void block_start(uint32_t p, uint32_t f)
+    {
+        atomicOr(&col[((p >> 5) - wbase) * 64u], f << (p & 31u)); // result unused: a plain LDS OR
+    }
 };
 
 // Stage the window that holds stream word `w0` (a multiple of ZJ_WIN_WORDS) into this lane's column.
-__device__ __forceinline__ void zj_stage_window(const uint32_t *stream, uint32_t w0, uint32_t *col)
+// The first `taken` (0..2) words are already in the reader's buffer: their slots start as bitmap words.
+__device__ __forceinline__ void zj_stage_window(const uint32_t *stream, uint32_t w0, uint32_t *col, uint32_t taken)
 {
     const uint4 *src = reinterpret_cast<const uint4 *>(stream + w0);
     const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
     const uint2 e = *reinterpret_cast<const uint2 *>(stream + w0 + 16);
-    col[0 * 64] = a.x; col[1 * 64] = a.y; col[2 * 64] = a.z; col[3 * 64] = a.w;
+    col[0 * 64] = taken > 0u ? 0u : a.x; col[1 * 64] = taken > 1u ? 0u : a.y; col[2 * 64] = a.z; col[3 * 64] = a.w;
     col[4 * 64] = b.x; col[5 * 64] = b.y; col[6 * 64] = b.z; col[7 * 64] = b.w;
     col[8 * 64] = c.x; col[9 * 64] = c.y; col[10 * 64] = c.z; col[11 * 64] = c.w;
     col[12 * 64] = d.x; col[13 * 64] = d.y; col[14 * 64] = d.z; col[15 * 64] = d.w;
@@ -144,22 +157,35 @@ __device__ __forceinline__ void zj_stage_window(const uint32_t *stream, uint32_t
 }
 
 // One window for the lanes of a wavefront that have `run` set: stage window `win` (index inside the
-// segment) of the lane's stream, then walk the symbols that start before the window's end or `end`,
-// whichever comes first.  The reader carries over from window to window; `primed` says whether it has
-// been positioned yet.  Returns the number of blocks that began.
-template <bool INDEX>
-__device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *stream, const uint32_t *lut,
-                                                   const ZjCanon *canon, uint32_t selw, uint32_t bpm, ZjState &st,
-                                                   uint32_t win, uint32_t end, ZjIndexOut *io, uint32_t *col,
-                                                   ZjBitsLds &bits, bool &primed)
+// segment) of the lane's stream, walk the symbols that start before the window's end or `end`,
+// whichever comes first, and store the window's bitmap words.  The reader carries over from window
+// to window; `primed` says whether it has been positioned yet.  Returns the number of blocks that
+// began in the window.
+__device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *stream, uint32_t *bitmap,
+                                                   const uint16_t *lut, const ZjCanon *canon, uint32_t selw,
+                                                   uint32_t bpm, ZjState &st, uint32_t win, uint32_t end,
+                                                   uint32_t *col, ZjBitsLds &bits, bool &primed)
 {
     uint32_t n = 0;
     if (run) {
-        zj_stage_window(stream, win * ZJ_WIN_WORDS, col);
         bits.wbase = win * ZJ_WIN_WORDS;
+        zj_stage_window(stream, win * ZJ_WIN_WORDS, col, primed ? bits.widx - bits.wbase : 0u);
         if (!primed) { bits.init(st.p); primed = true; }
         const uint32_t wend = (win + 1u) * ZJ_WIN_BITS;
-        n = zj_decode_run<ZjBitsLds, INDEX>(bits, lut, canon, selw, bpm, st, wend < end ? wend : end, io);
+        zj_decode_run<ZjBitsLds, ZjBitsLds>(bits, lut, canon, selw, bpm, st, wend < end ? wend : end, bits);
+        // slots the reader has not reached (the stream ended inside the window) still hold stream words
+        const uint32_t taken = bits.widx - bits.wbase;
+        uint32_t w[ZJ_WIN_WORDS];
+#pragma unroll
+        for (int i = 0; i < ZJ_WIN_WORDS; i++) {
+            w[i] = (uint32_t)i < taken ? col[i * 64] : 0u;
+            n += __popc(w[i]);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(bitmap + (size_t)win * ZJ_WIN_WORDS);
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        dst[2] = make_uint4(w[8], w[9], w[10], w[11]);
+        dst[3] = make_uint4(w[12], w[13], w[14], w[15]);
     }
     return n;
 }
@@ -245,20 +271,26 @@ __global__ __launch_bounds__(64) void zj_k0_unstuff(ZjParams P)
 // ---------------------------------------------------------------------------------- k1a: sync
 // 256 threads = 4 wavefronts = 4 chunks of 64 subsequences, all of one image (table set in LDS).
 // Round 0: every lane walks its own subsequence from the guessed state "a block starts here" and
-// leaves one record per window.  Round k: lane i walks on into subsequence i+k from the state it
-// carries, replacing the records it passes, until its state at a window end equals the record that is
-// already there -- from that point on the two walks coincide, so the lane is synchronised and stops.
-// The wavefront votes (ballot) on whether any lane still has to walk.  Dynamic LDS: 4 * nc * 64 words.
-extern __shared__ uint32_t zj_dyn_lds[];
+// leaves one record and one set of bitmap words per window.  Round k: lane i walks on into
+// subsequence i+k from the state it carries, replacing the records and bitmap words it passes, until
+// its state at a window end equals the record that is already there -- from that point on the two
+// walks coincide, so the lane is synchronised and stops.  The wavefront votes (ballot) on whether any
+// lane still has to walk.  Subsequences are long compared with the distance a wrong guess survives
+// (a few thousand bits on photographs), so the rounds after the first are short.
+// Records written by one lane are read by another lane of the same wavefront in a later round: the
+// stores are plain (write-through to L2), the loads bypass the per-CU cache, and every window step in
+// between waits for all outstanding memory operations of the wavefront.
+__device__ __forceinline__ uint32_t zj_load_coherent(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lut[ZJ_SET_ENTRIES];
+    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
     __shared__ uint32_t win[4][ZJ_WIN_SLOTS * 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t NC = P.nc, SB = P.subbits;
     uint32_t *col = &win[wave][lane];
-    volatile uint32_t *wrec = zj_dyn_lds + wave * NC * 64u; // [window c][lane]
     const uint32_t chunk = blockIdx.x * 4u + wave;
     const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
     const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
@@ -266,15 +298,18 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
     ZjSel sel = {im.bpm, im.dcsel, im.acsel};
     const uint32_t selw = zj_selword(sel);
-    for (uint32_t c = 0; c < NC; c++) wrec[c * 64u + lane] = 0;
     __syncthreads();
 
     const uint32_t seg = P.chunk_seg[chunk];
     if (seg == ZJ_NONE) return; // wave-uniform: a padding chunk
     const ZjSegDev sg = P.segs[seg];
-    const uint32_t jl = chunk * 64u + lane - sg.first_sub;
+    const uint32_t NC = sg.nc, SB = sg.subbits;
+    const uint32_t ch = chunk - (sg.first_sub >> 6);        // chunk inside the segment
+    uint32_t *rec = P.winfo + sg.first_win + (size_t)ch * 64u * NC; // [window c][lane]
+    const uint32_t jl = ch * 64u + lane;
     const uint32_t pay = P.seg_payload_bits[seg];
     const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
+    uint32_t *bitmap = reinterpret_cast<uint32_t *>(P.bitmap + sg.out_off);
     ZjBitsLds bits;
     bits.col = col;
     bool primed = false;
@@ -286,8 +321,8 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
             const bool run = act0 && st.p < end;
             if (!__any(run)) break;
             const uint32_t w = jl * NC + c;
-            const uint32_t n = zj_window_step<false>(run, stream, lut, canon, selw, sel.bpm, st, w, end, nullptr, col, bits, primed);
-            if (run) wrec[c * 64u + lane] = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
+            const uint32_t n = zj_window_step(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
+            if (run) rec[c * 64u + lane] = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
         }
     }
     bool done = !act0;
@@ -301,44 +336,41 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
             const bool run = act && st.p < end;
             if (!__any(run)) break;
             const uint32_t w = q * NC + c;
-            const uint32_t n = zj_window_step<false>(run, stream, lut, canon, selw, sel.bpm, st, w, end, nullptr, col, bits, primed);
+            const uint32_t n = zj_window_step(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
             if (run) {
                 const uint32_t nw = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
-                const uint32_t old = wrec[c * 64u + tgt];
-                wrec[c * 64u + tgt] = nw;
+                const uint32_t old = zj_load_coherent(&rec[c * 64u + tgt]);
+                rec[c * 64u + tgt] = nw;
                 if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0u) { act = false; done = true; }
             }
         }
     }
-    uint32_t *out = P.winfo + (size_t)chunk * 64u * NC;
-    for (uint32_t c = 0; c < NC; c++) out[c * 64u + lane] = wrec[c * 64u + lane];
 }
 
 // ---------------------------------------------------------------------------------- k1b: fix
 // One lane per chunk: starts from the state recorded at the end of the previous chunk and replaces
-// the window records of its own chunk until it meets a record that already agrees.
+// the window records and bitmap words of its own chunk until it meets a record that already agrees.
 __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
 {
-    const uint32_t ch = blockIdx.x * 64u + threadIdx.x;
-    if (ch >= P.nchunks) return;
-    const uint32_t seg = P.chunk_seg[ch];
+    const uint32_t chunk = blockIdx.x * 64u + threadIdx.x;
+    if (chunk >= P.nchunks) return;
+    const uint32_t seg = P.chunk_seg[chunk];
     if (seg == ZJ_NONE) return;
     const ZjSegDev sg = P.segs[seg];
-    if (ch * 64u == sg.first_sub) return; // the first chunk of a segment starts from the true state
-    const uint32_t SB = P.subbits, NC = P.nc;
+    if (chunk * 64u == sg.first_sub) return; // the first chunk of a segment starts from the true state
+    const uint32_t SB = sg.subbits, NC = sg.nc;
     const uint32_t pay = P.seg_payload_bits[seg];
-    const uint32_t q0 = ch * 64u - sg.first_sub;
+    const uint32_t q0 = chunk * 64u - sg.first_sub;
     if (!sub_active(sg, q0, SB, pay)) return;
     const ZjImgDev &im = P.imgs[sg.img];
-    const uint32_t *lut = P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES;
+    const uint16_t *lut = P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES;
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
     ZjSel sel = {im.bpm, im.dcsel, im.acsel};
     const uint32_t selw = zj_selword(sel);
     const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
-    uint32_t *rec = P.winfo + (size_t)sg.first_sub * NC;
+    uint32_t *bitmap = reinterpret_cast<uint32_t *>(P.bitmap + sg.out_off);
+    uint32_t *rec = P.winfo + sg.first_win;
     ZjState st = zj_unpack_state(rec[zj_rec_index(q0 - 1u, NC - 1u, NC)], q0 * SB);
-    ZjBits bits;
-    bits.init(stream, st.p);
     for (uint32_t t = 0; t < 64u; t++) {
         const uint32_t q = q0 + t;
         if (!sub_active(sg, q, SB, pay)) return;
@@ -347,8 +379,7 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
             if (st.p >= end) break;
             const uint32_t w = q * NC + c;
             const uint32_t wend = (w + 1u) * ZJ_WIN_BITS;
-            const uint32_t n = zj_decode_run<ZjBits, false>(bits, lut, canon, selw, sel.bpm, st, wend < end ? wend : end, nullptr);
-            const uint32_t nw = zj_pack_info(st, wend, n);
+            const uint32_t nw = zj_walk_window_direct(stream, bitmap, lut, canon, selw, sel.bpm, st, w, wend < end ? wend : end);
             const uint32_t idx = zj_rec_index(q, c, NC);
             const uint32_t old = rec[idx];
             rec[idx] = nw;
@@ -359,68 +390,59 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
 }
 
 // ---------------------------------------------------------------------------------- k1s: scan
-// One workgroup per segment: base[j] = number of blocks that begin before subsequence j.
+// One workgroup per segment, windows in stream order: wbase[w] = number of blocks that begin before
+// window w.
 __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
 {
     __shared__ uint32_t wsum[8];
     const uint32_t s = blockIdx.x;
     const ZjSegDev sg = P.segs[s];
-    const uint32_t NC = P.nc;
-    const uint32_t *rec = P.winfo + (size_t)sg.first_sub * NC;
+    const uint32_t NC = sg.nc;
+    const uint32_t pay = P.seg_payload_bits[s];
+    const uint32_t nwin = min(sg.nsub * NC, (pay + ZJ_WIN_BITS - 1u) / ZJ_WIN_BITS);
+    const uint32_t *rec = P.winfo + sg.first_win;
+    uint32_t *wb = P.wbase + sg.first_win;
     uint32_t carry = 0;
-    for (uint32_t t0 = 0; t0 < sg.nsub; t0 += 256u) {
-        const uint32_t q = t0 + threadIdx.x;
+    for (uint32_t t0 = 0; t0 < nwin; t0 += 256u) {
+        const uint32_t wi = t0 + threadIdx.x;
         uint32_t n = 0;
-        if (q < sg.nsub)
-            for (uint32_t c = 0; c < NC; c++) n += rec[zj_rec_index(q, c, NC)] >> 16;
+        if (wi < nwin) {
+            const uint32_t q = wi / NC, c = wi - q * NC;
+            n = rec[zj_rec_index(q, c, NC)] >> 16;
+        }
         uint32_t total;
         uint32_t inc = block_incl_scan<4>(n, wsum, &total);
-        if (q < sg.nsub) P.base[(size_t)sg.first_sub + q] = carry + inc - n;
+        if (wi < nwin) wb[wi] = carry + inc - n;
         carry += total;
     }
     if (threadIdx.x == 0) P.seg_found[s] = carry;
 }
 
-// ---------------------------------------------------------------------------------- k1i: index
-__global__ __launch_bounds__(256) void zj_k1i_index(ZjParams P)
+// ---------------------------------------------------------------------------------- k1p: positions
+// One lane per window: turns the window's bitmap words into entries of the block position list.
+__global__ __launch_bounds__(256) void zj_k1p_positions(ZjParams P)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lut[ZJ_SET_ENTRIES];
-    __shared__ uint32_t win[4][ZJ_WIN_SLOTS * 64];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t *col = &win[wave][lane];
-    const uint32_t chunk = blockIdx.x * 4u + wave;
-    const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
-    const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
-    load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
-    const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
-    ZjSel sel = {im.bpm, im.dcsel, im.acsel};
-    const uint32_t selw = zj_selword(sel);
-    __syncthreads();
-    const uint32_t seg = P.chunk_seg[chunk];
-    if (seg == ZJ_NONE) return; // wave-uniform
-    const ZjSegDev sg = P.segs[seg];
-    const uint32_t SB = P.subbits, NC = P.nc;
-    const uint32_t pay = P.seg_payload_bits[seg];
-    const size_t j = (size_t)chunk * 64u + lane;
-    const uint32_t jl = (uint32_t)(j - sg.first_sub);
-    const bool act = sub_active(sg, jl, SB, pay);
-    const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
-    const uint32_t *rec = P.winfo + (size_t)sg.first_sub * NC;
-    ZjState st = {jl * SB, 0, 0};
-    if (act && jl > 0) st = zj_unpack_state(rec[zj_rec_index(jl - 1u, NC - 1u, NC)], jl * SB);
-    ZjIndexOut io = {P.blockpos + sg.first_block, act ? P.base[j] : 0u, sg.nblocks};
-    const uint32_t end = act ? sub_end(jl, SB, pay) : 0u;
-    ZjBitsLds bits;
-    bits.col = col;
-    bool primed = false, bad = false;
-    for (uint32_t c = 0; c < NC; c++) {
-        const bool run = act && st.p < end;
-        if (!__any(run)) break;
-        const uint32_t w = jl * NC + c;
-        const uint32_t n = zj_window_step<true>(run, stream, lut, canon, selw, sel.bpm, st, w, end, &io, col, bits, primed);
-        if (run && zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n) != rec[zj_rec_index(jl, c, NC)]) bad = true;
+    const uint32_t s = P.ptile_seg[blockIdx.x];
+    const ZjSegDev sg = P.segs[s];
+    const uint32_t pay = P.seg_payload_bits[s];
+    const uint32_t nwin = min(sg.nsub * sg.nc, (pay + ZJ_WIN_BITS - 1u) / ZJ_WIN_BITS);
+    const uint32_t wi = (blockIdx.x - sg.first_ptile) * 256u + threadIdx.x;
+    if (wi >= nwin) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.bitmap + sg.out_off) + (size_t)wi * 4u;
+    const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+    const uint32_t w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    uint32_t g = P.wbase[sg.first_win + wi];
+    uint32_t *pos = P.blockpos + sg.first_block;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        uint32_t m = w[i];
+        while (m) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(m);
+            m &= m - 1u;
+            if (g < sg.nblocks) pos[g] = wi * ZJ_WIN_BITS + (uint32_t)i * 32u + bit;
+            g++;
+        }
     }
-    if (bad) atomicOr(&P.flags[1], 1u); // the chain of records is not consistent yet
 }
 
 // ---------------------------------------------------------------------------------- k1c: DC differences
@@ -544,6 +566,10 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
                 st = zj_decode_block(stream, lut, canon, (im.dcsel >> kb) & 1u, (im.acsel >> kb) & 1u, P.blockpos[g],
                                      P.dcabs[g], reinterpret_cast<int16_t *>(row32), &pend);
                 if (pend > P.seg_payload_bits[seg]) st |= 4u; // ZJ_ST_TRUNCATED
+                // a cleanly decoded block ends where the next one begins; if it does not, the position
+                // list does not describe the sequential decode
+                if (st == 0u && gs + 1u < min(P.seg_found[seg], P.segs[seg].nblocks) && P.blockpos[g + 1u] != pend)
+                    atomicOr(&P.flags[1], 1u);
             } else {
                 st = 4u;
             }
@@ -861,13 +887,13 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     hipMemsetAsync(P.flags, 0, 16, st);
     hipLaunchKernelGGL(zj_k0_unstuff, dim3(L.nseg), dim3(64), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
-    hipLaunchKernelGGL(zj_k1a_sync, dim3(L.nchunks / 4), dim3(256), 4u * P.nc * 64u * sizeof(uint32_t), st, P);
+    hipLaunchKernelGGL(zj_k1a_sync, dim3(L.nchunks / 4), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
     for (int i = 0; i < L.fix_iters; i++) hipLaunchKernelGGL(zj_k1b_fix, dim3((L.nchunks + 63) / 64), dim3(64), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
-    hipLaunchKernelGGL(zj_k1i_index, dim3(L.nchunks / 4), dim3(256), 0, st, P);
+    if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1c_dcdiff, dim3(L.nblk256), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.nseg), dim3(256), 0, st, P);
@@ -884,7 +910,7 @@ extern "C" void zj_launch_fix_only(const ZjParams &P, const ZjLaunch &L, hipStre
 extern "C" void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
 {
     hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(zj_k1i_index, dim3(L.nchunks / 4), dim3(256), 0, st, P);
+    if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1c_dcdiff, dim3(L.nblk256), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.nseg), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);

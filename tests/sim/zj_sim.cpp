@@ -31,7 +31,7 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
         if (t4[t]) { if (!zj_build_table(t4[t], &lut[t * ZJ_TBL_ENTRIES], &canon[t])) return ZJ_E_FORMAT; }
         else memset(&canon[t], 0, sizeof(ZjCanon));
     }
-    std::vector<uint32_t> wlut(ZJ_SET_ENTRIES);
+    std::vector<uint16_t> wlut(ZJ_SET_ENTRIES);
     for (int t = 0; t < 4; t++) zj_build_walk_table(&lut[t * ZJ_TBL_ENTRIES], t < 2, &wlut[t * ZJ_TBL_ENTRIES]);
     ZjSel sel = {bpm, 0, 0};
     uint32_t compsel = 0;
@@ -63,37 +63,33 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
         ust.resize(ust.size() + 1024, 0);
         while (ust.size() % 4) ust.push_back(0);
         const uint32_t *stream = (const uint32_t *)ust.data();
-        const uint32_t nsub = (uint32_t)(((end - beg) * 8 + subbits - 1) / subbits);
+        uint32_t SB, nsub;
+        zj_seg_layout((uint64_t)(end - beg) * 8u, subbits, &SB, &nsub);
         const uint32_t nchunk = (nsub + 63) / 64;
-        const uint32_t NC = subbits / ZJ_WIN_BITS;
+        const uint32_t NC = SB / ZJ_WIN_BITS;
         const uint32_t selw = zj_selword(sel);
-        std::vector<uint32_t> rec((size_t)nchunk * 64 * NC + 1, 0), base(nchunk * 64 + 1, 0);
-        auto active = [&](uint32_t q) { return q < nsub && (uint64_t)q * subbits < pay; };
-        auto send = [&](uint32_t q) { uint64_t e = (uint64_t)(q + 1) * subbits; return e < pay ? (uint32_t)e : pay; };
+        std::vector<uint32_t> rec((size_t)nchunk * 64 * NC + 1, 0), wbase((size_t)nchunk * 64 * NC + 1, 0);
+        std::vector<uint32_t> bitmap(ust.size() / 4 + 64, 0);
+        auto active = [&](uint32_t q) { return q < nsub && (uint64_t)q * SB < pay; };
+        auto send = [&](uint32_t q) { uint64_t e = (uint64_t)(q + 1) * SB; return e < pay ? (uint32_t)e : pay; };
         // one window of a walk: symbols that start before the end of window w (or `e`), on a reader that
         // is re-positioned every time (the kernels carry the reader over; the bits are the same)
         auto window = [&](ZjState &st, uint32_t w, uint32_t e) {
             uint32_t wend = (w + 1) * ZJ_WIN_BITS;
-            uint32_t stop = wend < e ? wend : e;
-            if (st.p >= stop) return 0u;
-            ZjBits bits;
-            bits.init(stream, st.p);
-            return zj_decode_run<ZjBits, false>(bits, wlut.data(), canon, selw, bpm, st, stop, nullptr);
+            return zj_walk_window_direct(stream, bitmap.data(), wlut.data(), canon, selw, bpm, st, w, wend < e ? wend : e);
         };
-        // k1a: per chunk, rounds in lock step, one record per window
+        // k1a: per chunk, rounds in lock step, one record and one set of bitmap words per window
         for (uint32_t ch = 0; ch < nchunk; ch++) {
             ZjState st[64];
             bool done[64];
             for (uint32_t l = 0; l < 64; l++) {
                 uint32_t jl = ch * 64 + l;
                 done[l] = !active(jl);
-                st[l] = {jl * subbits, 0, 0};
+                st[l] = {jl * SB, 0, 0};
                 if (done[l]) continue;
                 for (uint32_t c = 0; c < NC; c++) {
                     if (st[l].p >= send(jl)) break;
-                    uint32_t w = jl * NC + c;
-                    uint32_t n = window(st[l], w, send(jl));
-                    rec[zj_rec_index(jl, c, NC)] = zj_pack_info(st[l], (w + 1) * ZJ_WIN_BITS, n);
+                    rec[zj_rec_index(jl, c, NC)] = window(st[l], jl * NC + c, send(jl));
                 }
             }
             uint32_t rounds = 0;
@@ -113,9 +109,7 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
                     uint32_t q = ch * 64 + l + k2;
                     for (uint32_t c = 0; c < NC; c++) {
                         if (st[l].p >= send(q)) break;
-                        uint32_t w = q * NC + c;
-                        uint32_t n = window(st[l], w, send(q));
-                        uint32_t nw = zj_pack_info(st[l], (w + 1) * ZJ_WIN_BITS, n);
+                        uint32_t nw = window(st[l], q * NC + c, send(q));
                         uint32_t &r = rec[zj_rec_index(q, c, NC)];
                         uint32_t old = r;
                         r = nw;
@@ -131,7 +125,7 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
         for (uint32_t ch = 1; ch < nchunk; ch++) {
             uint32_t q0 = ch * 64;
             if (!active(q0)) continue;
-            ZjState st = zj_unpack_state(rec[zj_rec_index(q0 - 1, NC - 1, NC)], q0 * subbits);
+            ZjState st = zj_unpack_state(rec[zj_rec_index(q0 - 1, NC - 1, NC)], q0 * SB);
             uint32_t steps = 0;
             bool synced = false;
             for (uint32_t t = 0; t < 64 && !synced; t++) {
@@ -140,9 +134,7 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
                 for (uint32_t c = 0; c < NC; c++) {
                     if (st.p >= send(q)) break;
                     steps++;
-                    uint32_t w = q * NC + c;
-                    uint32_t n = window(st, w, send(q));
-                    uint32_t nw = zj_pack_info(st, (w + 1) * ZJ_WIN_BITS, n);
+                    uint32_t nw = window(st, q * NC + c, send(q));
                     uint32_t &r = rec[zj_rec_index(q, c, NC)];
                     uint32_t old = r;
                     r = nw;
@@ -153,29 +145,25 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
             stats->fix_steps_max = std::max(stats->fix_steps_max, steps);
             stats->fix_steps_sum += steps;
         }
-        // k1s
+        // k1s: window bases in stream order
+        const uint32_t nwin = std::min(nsub * NC, (pay + ZJ_WIN_BITS - 1) / ZJ_WIN_BITS);
         uint32_t carry = 0;
-        for (uint32_t q = 0; q < nsub; q++) {
-            base[q] = carry;
-            for (uint32_t c = 0; c < NC; c++) carry += rec[zj_rec_index(q, c, NC)] >> 16;
+        for (uint32_t wi = 0; wi < nwin; wi++) {
+            wbase[wi] = carry;
+            carry += rec[zj_rec_index(wi / NC, wi % NC, NC)] >> 16;
         }
         const uint32_t found = std::min(carry, nblocks);
-        // k1i
+        // k1p: bitmap -> block positions
         std::vector<uint32_t> blockpos(nblocks + 1, 0);
         std::vector<int16_t> dcabs(nblocks + 1, 0);
-        for (uint32_t q = 0; q < nsub; q++) {
-            if (!active(q)) continue;
-            ZjState st = {q * subbits, 0, 0};
-            if (q > 0) st = zj_unpack_state(rec[zj_rec_index(q - 1, NC - 1, NC)], q * subbits);
-            ZjIndexOut io = {blockpos.data(), base[q], nblocks};
-            for (uint32_t c = 0; c < NC; c++) {
-                if (st.p >= send(q)) break;
-                uint32_t w = q * NC + c, wend = (w + 1) * ZJ_WIN_BITS;
-                ZjBits bits;
-                bits.init(stream, st.p);
-                uint32_t n = zj_decode_run<ZjBits, true>(bits, wlut.data(), canon, selw, bpm, st, wend < send(q) ? wend : send(q), &io);
-                if (zj_pack_info(st, wend, n) != rec[zj_rec_index(q, c, NC)]) stats->verify_fail = 1;
-            }
+        for (uint32_t wi = 0; wi < nwin; wi++) {
+            uint32_t g = wbase[wi];
+            for (uint32_t i = 0; i < ZJ_WIN_WORDS; i++)
+                for (uint32_t bit = 0; bit < 32; bit++)
+                    if ((bitmap[(size_t)wi * ZJ_WIN_WORDS + i] >> bit) & 1u) {
+                        if (g < nblocks) blockpos[g] = wi * ZJ_WIN_BITS + i * 32 + bit;
+                        g++;
+                    }
         }
         // k1d
         uint32_t run[3] = {0, 0, 0};
@@ -197,6 +185,7 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
             uint32_t s = zj_decode_block(stream, lut.data(), canon, (sel.dcsel >> kb) & 1, (sel.acsel >> kb) & 1, blockpos[g],
                                          dcabs[g], row, &pend);
             if (pend > pay) s |= ZJ_ST_TRUNCATED;
+            if (s == 0 && g + 1 < found && blockpos[g + 1] != pend) stats->verify_fail = 1;
             status |= s;
             memcpy(qc + (size_t)g * 64, rowbuf, 128);
         }

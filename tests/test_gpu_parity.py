@@ -39,7 +39,7 @@ def assert_same(data, rgb, status, qcoef, dq=None):
 
 
 @pytest.mark.parametrize("name", [f for f in FIXTURES if f != "large.jpg"])
-@pytest.mark.parametrize("subbits", [512, 1024, 8192])
+@pytest.mark.parametrize("subbits", [0, 512, 1024, 8192, 65536])
 def test_fixture_parity(ctx, name, subbits):
     data = fixture_bytes(name)
     img = J.ParsedImage(data)

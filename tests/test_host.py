@@ -89,7 +89,7 @@ def test_restart_offsets_and_bands():
     assert full.rgb[32:80].shape == (48, 256, 3)
 
 
-SIM_CASES = [(f, sb) for f in ["porsche.jpg", "profile.jpg", "test-baseline.jpg", "out.jpg"] for sb in (512, 1024, 4096)]
+SIM_CASES = [(f, sb) for f in ["porsche.jpg", "profile.jpg", "test-baseline.jpg", "out.jpg"] for sb in (512, 1024, 4096, 65536)]
 
 
 @pytest.mark.parametrize("name,subbits", SIM_CASES)
@@ -110,7 +110,7 @@ def test_stage1_walk_fixtures(name, subbits):
 def test_stage1_walk_synthetic(params):
     data = synth.encode(*params)
     want = oracle.decode(data, want_rgb=False).qcoef
-    for sb in (512, 2048):
+    for sb in (512, 2048, 20000):
         rc, st, q, ss = sim_decode(data, sb)
         assert rc == 0 and st == 0 and ss.verify_fail == 0
         assert np.array_equal(q, want)

@@ -152,7 +152,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
 
     b->imgs.resize(n);
     b->unsupported.assign(n, 0);
-    std::vector<uint32_t> chunk_seg, blk256_img, k1w_img, ptile_seg;
+    std::vector<uint32_t> chunk_seg, blk256_img, k1w_img, ptile_seg, tile_seg;
     uint64_t nwin_total = 0;
     std::vector<uint32_t> k2_grp[4], k2_img[4]; // stage-2 workgroups per sampling layout
     std::vector<uint16_t> luts;
@@ -258,6 +258,10 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             const uint32_t nchunk = (s.nsub + 63) / 64;
             s.first_win = (uint32_t)nwin_total;
             nwin_total += (uint64_t)nchunk * 64u * s.nc;
+            s.first_tile = (uint32_t)tile_seg.size();
+            s.ntiles = (uint32_t)((s.raw_end - (s.raw_begin & ~15ull) + 16383u) / 16384u);
+            if (s.ntiles == 0) s.ntiles = 1; // an empty segment still publishes its payload length
+            for (uint32_t t = 0; t < s.ntiles; t++) tile_seg.push_back((uint32_t)b->segs.size());
             s.first_ptile = (uint32_t)ptile_seg.size();
             for (uint64_t w = 0; w < (uint64_t)s.nsub * s.nc; w += 256u) ptile_seg.push_back((uint32_t)b->segs.size());
             for (uint32_t c = 0; c < nchunk; c++) chunk_seg.push_back((uint32_t)b->segs.size());
@@ -300,6 +304,9 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.blk256_img = dev_upload(b, blk256_img);
     P.k1w_img = dev_upload(b, k1w_img);
     P.ptile_seg = dev_upload(b, ptile_seg);
+    P.tile_seg = dev_upload(b, tile_seg);
+    P.tile_status = dev_alloc<uint64_t>(b, tile_seg.size() + 1, true);
+    P.tile_ticket = P.tile_status ? reinterpret_cast<uint32_t *>(P.tile_status + tile_seg.size()) : nullptr;
     std::vector<uint32_t> strip_grp_all, strip_img_all;
     for (int c = 0; c < 4; c++) {
         b->L.k2_first[c] = (uint32_t)strip_grp_all.size();
@@ -335,7 +342,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.rgb_stride = b->d_stride;
     P.nchunks = (uint32_t)chunk_seg.size();
     ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.wluts && P.canons && P.qts && raw && P.ust &&
-         P.seg_payload_bits && P.seg_found && P.winfo && P.wbase && P.bitmap && P.ptile_seg && P.blockpos && P.dcabs && P.qcoef && P.status &&
+         P.seg_payload_bits && P.seg_found && P.winfo && P.wbase && P.bitmap && P.ptile_seg && P.tile_seg && P.tile_status && P.blockpos && P.dcabs && P.qcoef && P.status &&
          P.flags && b->d_rgb && b->d_stride;
     if (ok) ok = hip_ok(ctx, hipHostMalloc((void **)&b->h_rgb, (n ? n : 1) * sizeof(uint8_t *), hipHostMallocDefault), "hipHostMalloc") &&
                  hip_ok(ctx, hipHostMalloc((void **)&b->h_stride, (n ? n : 1) * sizeof(size_t), hipHostMallocDefault), "hipHostMalloc") &&
@@ -356,6 +363,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     b->L.nblk256 = (uint32_t)blk256_img.size();
     b->L.nk1w = (uint32_t)k1w_img.size();
     b->L.nptiles = (uint32_t)ptile_seg.size();
+    b->L.ntiles = (uint32_t)tile_seg.size();
     b->L.nstrips = (uint32_t)strip_grp_all.size();
     b->L.fix_iters = 1;
     return b;

@@ -191,81 +191,134 @@ __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *str
 }
 
 // ---------------------------------------------------------------------------------- k0: unstuff
-// One wavefront per segment.  Walks the raw bytes in 1 KiB tiles (16 bytes per lane), drops every 00
-// that follows an FF, and appends the kept bytes to an LDS buffer that is flushed in aligned
-// 16-byte pieces.  Writes the payload length and zero-fills the rest of the segment's slot.
-__global__ __launch_bounds__(64) void zj_k0_unstuff(ZjParams P)
+// Drops every 00 that follows an FF (src/bitstream.rs:37-50) -- a stream compaction, done in one pass
+// over tiles of 16 KiB of raw bytes (256 threads x 64 bytes).  A tile counts its kept bytes, gets the
+// number of bytes kept before it in the same segment from its predecessors (decoupled look-back: a
+// tile publishes its own count first and its inclusive prefix when known, and walks backwards over
+// the published words of the tiles before it), compacts into LDS and copies out in aligned 16-byte
+// pieces.  Tiles are taken in ticket order, so every tile a workgroup waits for is already running.
+// The unstuffed arena starts zeroed and the same bytes are written on every decode of a batch, so the
+// bytes behind a segment's payload stay zero (the reference pads with zeros, src/bitstream.rs:80-84).
+#define ZJ_K0_TILE 16384u
+#define ZJ_TS_AGG (1ull << 32)
+#define ZJ_TS_INCL (2ull << 32)
+
+__global__ __launch_bounds__(256) void zj_k0_unstuff(ZjParams P)
 {
-    const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint8_t buf[ZJ_K0_TILE + 48];
+    __shared__ uint32_t wsum[8];
+    __shared__ uint32_t s_tile, s_prefix;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) s_tile = atomicAdd(P.tile_ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t s = P.tile_seg[tile];
     const ZjSegDev sg = P.segs[s];
-    __shared__ __attribute__((aligned(16))) uint8_t buf[1024 + 32];
-
-    const uint8_t *raw = P.raw;
-    uint8_t *out = P.ust + sg.out_off;
+    const uint32_t tj = tile - sg.first_tile;
     const uint64_t a0 = sg.raw_begin & ~15ull;
-    uint32_t rem = 0, outpos = 0, carry = 0;
+    const uint64_t my = a0 + (uint64_t)tj * ZJ_K0_TILE + (uint64_t)tid * 64u;
+    const uint8_t *raw = P.raw;
 
-    auto load_tile = [&](uint64_t a) -> uint4 {
-        uint64_t my = a + (uint64_t)lane * 16u;
-        if (my < sg.raw_end) return *reinterpret_cast<const uint4 *>(raw + my);
-        return make_uint4(0, 0, 0, 0);
-    };
-
-    uint4 cur = load_tile(a0);
-    for (uint64_t a = a0; a < sg.raw_end; a += 1024u) {
-        uint4 nxt = load_tile(a + 1024u);
-        const uint64_t my = a + (uint64_t)lane * 16u;
-        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
-        // is the last byte of this lane an in-range FF?  (needed by the next lane / next tile)
-        uint32_t lastff = ((w[3] >> 24) == 0xFFu) && (my + 15u >= sg.raw_begin) && (my + 15u < sg.raw_end);
-        uint32_t prevff = __shfl_up(lastff, 1, 64);
-        if (lane == 0) prevff = carry;
-        carry = __shfl(lastff, 63, 64);
-
-        uint32_t keep = 0, pf = prevff;
+    uint32_t w[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            uint32_t byte = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            uint64_t pos = my + (uint64_t)k;
-            bool inr = pos >= sg.raw_begin && pos < sg.raw_end;
-            bool drop = (byte == 0u) && pf;
-            if (inr && !drop) keep |= 1u << k;
+    for (int i = 0; i < 4; i++) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (my + 16u * i < sg.raw_end) v = *reinterpret_cast<const uint4 *>(raw + my + 16u * i);
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    // bytes of this thread that belong to the segment: [lo, hi) of 0..64 (signed differences, clamped)
+    const int64_t dlo = (int64_t)sg.raw_begin - (int64_t)my, dhi = (int64_t)sg.raw_end - (int64_t)my;
+    const uint32_t lo = dlo <= 0 ? 0u : (dlo >= 64 ? 64u : (uint32_t)dlo);
+    const uint32_t hi = dhi <= 0 ? 0u : (dhi >= 64 ? 64u : (uint32_t)dhi);
+    uint32_t pf = 0; // is the byte before this thread's first byte an FF of the segment
+    if (dlo < 0 && dhi >= 0) pf = raw[my - 1] == 0xFFu;
+
+    // kill[j]: bit 7 of byte k set when byte 4j+k is not kept (a stuffed 00, or outside the segment)
+    uint32_t kill[16];
+    uint32_t n;
+    if (__all(lo == 0u && hi == 64u)) {
+        // whole wavefront inside the segment (all but the first and last tile): word-parallel byte tests
+        uint32_t fprev = pf ? 0x80000000u : 0u, ndrop = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t x = w[j], y = ~x;
+            const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); // bytes equal to 00
+            const uint32_t f = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu); // bytes equal to FF
+            const uint32_t before = __builtin_amdgcn_alignbyte(f, fprev, 3);          // FF flag of the byte before
+            kill[j] = z & before;
+            ndrop += __popc(kill[j]);
+            fprev = f;
+        }
+        n = 64u - ndrop;
+    } else {
+        uint64_t keep = 0;
+#pragma unroll
+        for (int k = 0; k < 64; k++) {
+            const uint32_t byte = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            const bool inr = (uint32_t)k >= lo && (uint32_t)k < hi;
+            const bool drop = (byte == 0u) && pf;
+            if (inr && !drop) keep |= 1ull << k;
             pf = inr && (byte == 0xFFu);
         }
-        uint32_t n = __popc(keep);
-        uint32_t inc = wave_incl_scan(n, lane);
-        uint32_t total = __shfl(inc, 63, 64);
-        uint32_t o = rem + inc - n;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            if (keep & (1u << k)) buf[o++] = (uint8_t)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+        for (int j = 0; j < 16; j++) {
+            const uint32_t nib = (uint32_t)(keep >> (4 * j)) & 15u;
+            const uint32_t spread = (nib | (nib << 7) | (nib << 14) | (nib << 21)) & 0x01010101u;
+            kill[j] = (spread << 7) ^ 0x80808080u;
         }
-        __syncthreads();
-        const uint32_t have = rem + total;
-        const uint32_t full = have & ~15u;
-        if (lane * 16u < full) {
-            uint4 v = *reinterpret_cast<const uint4 *>(buf + lane * 16u);
-            *reinterpret_cast<uint4 *>(out + outpos + lane * 16u) = v;
-        }
-        uint8_t tmp = 0;
-        const uint32_t left = have - full;
-        if (full > 0 && lane < left) tmp = buf[full + lane];
-        __syncthreads();
-        if (full > 0 && lane < left) buf[lane] = tmp;
-        __syncthreads();
-        rem = left;
-        outpos += full;
-        cur = nxt;
+        n = (uint32_t)__popcll(keep);
     }
-    // tail: the last partial piece, then zeros up to the end of the slot
-    if (lane >= rem && lane < 16u) buf[lane] = 0;
+    uint32_t total;
+    const uint32_t inc = block_incl_scan<4>(n, wsum, &total);
+
+    if (tid == 0) {
+        uint32_t excl = 0;
+        if (tj > 0) {
+            __hip_atomic_store(&P.tile_status[tile], ZJ_TS_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t j = tile - 1u;
+            for (;;) {
+                const uint64_t sv = __hip_atomic_load(&P.tile_status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((sv >> 32) == 0) { __builtin_amdgcn_s_sleep(2); continue; }
+                excl += (uint32_t)sv;
+                if ((sv >> 32) == 2u) break; // inclusive prefix: everything before it is in
+                j--;                          // the first tile of a segment always publishes an inclusive prefix
+            }
+        }
+        __hip_atomic_store(&P.tile_status[tile], ZJ_TS_INCL | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_prefix = excl;
+        if (tile + 1u == sg.first_tile + sg.ntiles) P.seg_payload_bits[s] = (excl + total) * 8u;
+    }
     __syncthreads();
-    for (uint32_t off = outpos + lane * 16u; off < sg.out_cap; off += 1024u) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (off == outpos && rem > 0) v = *reinterpret_cast<const uint4 *>(buf);
-        *reinterpret_cast<uint4 *>(out + off) = v;
+    const uint32_t prefix = s_prefix;
+    const uint32_t shift = prefix & 15u; // LDS position = global position mod 16, so pieces line up
+    {
+        // every byte is stored at the position of the next kept byte: a byte that is not kept is
+        // overwritten by the kept byte that follows it in the same thread (LDS stores of a lane are
+        // executed in order); only a thread's last byte has no successor and goes to a spare slot
+        uint32_t o = shift + inc - n;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t dead = (kill[j] >> (8 * k + 7)) & 1u;
+                const uint32_t at = (j == 15 && k == 3 && dead) ? ZJ_K0_TILE + 32u : o;
+                buf[at] = (uint8_t)(w[j] >> (8 * k));
+                o += 1u - dead;
+            }
+        }
     }
-    if (lane == 0) P.seg_payload_bits[s] = (outpos + rem) * 8u;
+    __syncthreads();
+    uint8_t *out = P.ust + sg.out_off + (prefix - shift);
+    const uint32_t endpos = shift + total;
+    for (uint32_t pc = tid; pc * 16u < endpos; pc += 256u) {
+        const uint32_t b0 = pc * 16u;
+        if (b0 >= shift && b0 + 16u <= endpos) {
+            *reinterpret_cast<uint4 *>(out + b0) = *reinterpret_cast<const uint4 *>(buf + b0);
+        } else { // a piece shared with the neighbouring tile: only this tile's bytes
+            for (uint32_t k = 0; k < 16u; k++)
+                if (b0 + k >= shift && b0 + k < endpos) out[b0 + k] = buf[b0 + k];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------- k1a: sync
@@ -348,12 +401,29 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
 }
 
 // ---------------------------------------------------------------------------------- k1b: fix
-// One lane per chunk: starts from the state recorded at the end of the previous chunk and replaces
-// the window records and bitmap words of its own chunk until it meets a record that already agrees.
+// One lane per chunk (one wavefront per group of four chunks, which share an image and so a table
+// set in LDS): starts from the state recorded at the end of the previous chunk and replaces the window
+// records and bitmap words of its own chunk until it meets a record that already agrees.
+struct ZjEmitCol {
+    uint32_t *col;  // bitmap word s of the current window at col[s * 64]
+    uint32_t wbase; // stream word of slot 0
+    __device__ __forceinline__ void block_start(uint32_t p, uint32_t f)
+    {
+        atomicOr(&col[((p >> 5) - wbase) * 64u], f << (p & 31u));
+    }
+};
+
 __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
 {
-    const uint32_t chunk = blockIdx.x * 64u + threadIdx.x;
-    if (chunk >= P.nchunks) return;
+    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
+    __shared__ uint32_t bmp[ZJ_WIN_WORDS * 64];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
+    const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
+    load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
+    __syncthreads();
+    if (lane >= 4u) return;
+    const uint32_t chunk = blockIdx.x * 4u + lane;
     const uint32_t seg = P.chunk_seg[chunk];
     if (seg == ZJ_NONE) return;
     const ZjSegDev sg = P.segs[seg];
@@ -362,8 +432,6 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
     const uint32_t pay = P.seg_payload_bits[seg];
     const uint32_t q0 = chunk * 64u - sg.first_sub;
     if (!sub_active(sg, q0, SB, pay)) return;
-    const ZjImgDev &im = P.imgs[sg.img];
-    const uint16_t *lut = P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES;
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
     ZjSel sel = {im.bpm, im.dcsel, im.acsel};
     const uint32_t selw = zj_selword(sel);
@@ -371,6 +439,9 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
     uint32_t *bitmap = reinterpret_cast<uint32_t *>(P.bitmap + sg.out_off);
     uint32_t *rec = P.winfo + sg.first_win;
     ZjState st = zj_unpack_state(rec[zj_rec_index(q0 - 1u, NC - 1u, NC)], q0 * SB);
+    ZjBits bits;
+    bits.init(stream, st.p);
+    ZjEmitCol em = {&bmp[lane], 0};
     for (uint32_t t = 0; t < 64u; t++) {
         const uint32_t q = q0 + t;
         if (!sub_active(sg, q, SB, pay)) return;
@@ -379,7 +450,19 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
             if (st.p >= end) break;
             const uint32_t w = q * NC + c;
             const uint32_t wend = (w + 1u) * ZJ_WIN_BITS;
-            const uint32_t nw = zj_walk_window_direct(stream, bitmap, lut, canon, selw, sel.bpm, st, w, wend < end ? wend : end);
+#pragma unroll
+            for (int i = 0; i < ZJ_WIN_WORDS; i++) em.col[i * 64] = 0;
+            em.wbase = w * ZJ_WIN_WORDS;
+            zj_decode_run<ZjBits, ZjEmitCol>(bits, lut, canon, selw, sel.bpm, st, wend < end ? wend : end, em);
+            uint32_t bw[ZJ_WIN_WORDS], n = 0;
+#pragma unroll
+            for (int i = 0; i < ZJ_WIN_WORDS; i++) { bw[i] = em.col[i * 64]; n += __popc(bw[i]); }
+            uint4 *dst = reinterpret_cast<uint4 *>(bitmap + (size_t)w * ZJ_WIN_WORDS);
+            dst[0] = make_uint4(bw[0], bw[1], bw[2], bw[3]);
+            dst[1] = make_uint4(bw[4], bw[5], bw[6], bw[7]);
+            dst[2] = make_uint4(bw[8], bw[9], bw[10], bw[11]);
+            dst[3] = make_uint4(bw[12], bw[13], bw[14], bw[15]);
+            const uint32_t nw = zj_pack_info(st, wend, n);
             const uint32_t idx = zj_rec_index(q, c, NC);
             const uint32_t old = rec[idx];
             rec[idx] = nw;
@@ -885,11 +968,12 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     int e = 0;
     if (ev) hipEventRecord(ev[e++], st);
     hipMemsetAsync(P.flags, 0, 16, st);
-    hipLaunchKernelGGL(zj_k0_unstuff, dim3(L.nseg), dim3(64), 0, st, P);
+    hipMemsetAsync(P.tile_status, 0, ((size_t)L.ntiles + 1u) * sizeof(uint64_t), st);
+    if (L.ntiles) hipLaunchKernelGGL(zj_k0_unstuff, dim3(L.ntiles), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1a_sync, dim3(L.nchunks / 4), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
-    for (int i = 0; i < L.fix_iters; i++) hipLaunchKernelGGL(zj_k1b_fix, dim3((L.nchunks + 63) / 64), dim3(64), 0, st, P);
+    for (int i = 0; i < L.fix_iters; i++) hipLaunchKernelGGL(zj_k1b_fix, dim3(L.nchunks / 4), dim3(64), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
@@ -904,7 +988,7 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
 
 extern "C" void zj_launch_fix_only(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
 {
-    hipLaunchKernelGGL(zj_k1b_fix, dim3((L.nchunks + 63) / 64), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(zj_k1b_fix, dim3(L.nchunks / 4), dim3(64), 0, st, P);
 }
 
 extern "C" void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipStream_t st)

@@ -51,7 +51,7 @@ def main():
             r["hbm_traffic_bytes"] = r["hbm_read_bytes_corrected"] + r["hbm_write_bytes"]
         if r.get("TCC_HIT_sum") is not None and (r.get("TCC_HIT_sum", 0) + r.get("TCC_MISS_sum", 0)) > 0:
             r["l2_hit_rate"] = r["TCC_HIT_sum"] / (r["TCC_HIT_sum"] + r["TCC_MISS_sum"])
-    print(json.dumps({k: v for k, v in sorted(res.items()) if k.startswith("zj_")}, indent=1, sort_keys=True))
+    print(json.dumps({k: v for k, v in sorted(res.items()) if "zj_" in k}, indent=1, sort_keys=True))
 
 
 if __name__ == "__main__":

@@ -95,65 +95,74 @@ __device__ __forceinline__ void load_lut_to_lds(T *lds, const T *src)
 // its own stretch in a private column of LDS -- ZJ_WIN_WORDS words plus two words of look-ahead,
 // word w of lane l at [w][l], so the column reads are bank-conflict free -- with all lanes of the
 // wavefront staging at the same moment, and the symbol loop refills from LDS.
-#define ZJ_WIN_SLOTS (ZJ_WIN_WORDS + 2)
+#define ZJ_WIN_SLOTS (ZJ_WIN_WORDS + 3)
 
-// The block-start bitmap of the window shares the column: a slot whose stream word has been taken
-// into the reader's buffer is cleared at that moment and from then on collects the bitmap word of the
-// same index (a block can only start at a bit the reader has already taken).
+// The reader keeps the two stream words around the current bit (already byte-swapped to MSB-first) in
+// registers and fetches the word after them from the column on every symbol, so that moving on to the
+// next word is a handful of selects instead of a branch that some lane of the wavefront takes on
+// almost every symbol.
+// The block-start bitmap of the window shares the column: the bitmap word of the stream word that
+// holds the current bit is collected in a register and stored to that word's slot on every symbol
+// (the slot's stream word already sits in the reader's registers), so once the reader has moved on, the
+// slot holds the finished bitmap word.
 struct ZjBitsLds {
-    uint32_t *col;  // this lane's column: word slot s at col[s * 64]
-    uint32_t widx;  // next stream word to take
-    uint32_t wbase; // stream word held in slot 0
-    uint64_t buf;
-    int32_t cnt;
+    uint32_t *slot; // slot of the stream word that holds the current bit; the column's pitch is 64 words
+    uint32_t w0, w1; // that word and the next one
+    uint32_t o;      // bits of w0 already consumed, 0..31
+    uint32_t bm;     // block starts seen in w0's word
+    uint32_t nxt;    // the word after w1, fetched by top32()
 
-    __device__ __forceinline__ uint32_t take_word()
+    __device__ __forceinline__ void init(uint32_t *col, uint32_t wbase, uint32_t bitpos)
     {
-        uint32_t *slot = &col[(widx - wbase) * 64u];
-        const uint32_t w = *slot;
-        *slot = 0;
-        widx++;
-        return __builtin_bswap32(w);
+        slot = col + ((bitpos >> 5) - wbase) * 64u;
+        w0 = slot[0];
+        w1 = slot[64];
+        o = bitpos & 31u;
+        bm = 0;
     }
-    __device__ __forceinline__ void init(uint32_t bitpos)
+    // the column was restaged for the window that starts at stream word `wbase`
+    __device__ __forceinline__ void rebase(uint32_t *col, uint32_t wbase, uint32_t bitpos)
     {
-        widx = bitpos >> 5;
-        uint64_t w0 = take_word();
-        uint64_t w1 = take_word();
-        const uint32_t sh = bitpos & 31u;
-        buf = ((w0 << 32) | w1) << sh;
-        cnt = 64 - (int32_t)sh;
+        slot = col + ((bitpos >> 5) - wbase) * 64u;
     }
-    __device__ __forceinline__ uint32_t top32() const { return (uint32_t)(buf >> 32); }
-    __device__ __forceinline__ void skip(uint32_t n)
+    __device__ __forceinline__ uint32_t top32()
     {
-        buf <<= n;
-        cnt -= (int32_t)n;
-        if (cnt <= 32) { // a branch, not a select: in the later rounds of the sync pass few lanes are live
-            const uint64_t w = take_word();
-            buf |= w << (32 - cnt);
-            cnt += 32;
-        }
+        nxt = slot[128];
+        return (uint32_t)(((((uint64_t)w0 << 32) | w1) << o) >> 32);
     }
-    // a block's DC symbol starts at bit p (f = 1) or the symbol at p is something else (f = 0)
-    __device__ __forceinline__ void block_start(uint32_t p, uint32_t f)
+    // a block's DC symbol starts at the current bit (f = 1) or the symbol there is something else (f = 0)
+    __device__ __forceinline__ void block_start(uint32_t, uint32_t f)
     {
-        atomicOr(&col[((p >> 5) - wbase) * 64u], f << (p & 31u)); // result unused: a plain LDS OR
+        bm |= f << o;
+        slot[0] = bm;
     }
+    __device__ __forceinline__ void skip(uint32_t n) // n <= 32
+    {
+        o += n;
+        const bool adv = o >= 32u;
+        w0 = adv ? w1 : w0;
+        w1 = adv ? nxt : w1;
+        bm = adv ? 0u : bm;
+        slot += adv ? 64 : 0;
+        o &= 31u;
+    }
+    __device__ __forceinline__ uint32_t words_done(const uint32_t *col) const { return (uint32_t)(slot - col) >> 6; }
 };
 
-// Stage the window that holds stream word `w0` (a multiple of ZJ_WIN_WORDS) into this lane's column.
-// The first `taken` (0..2) words are already in the reader's buffer: their slots start as bitmap words.
-__device__ __forceinline__ void zj_stage_window(const uint32_t *stream, uint32_t w0, uint32_t *col, uint32_t taken)
+// Stage the window that holds stream word `w0` (a multiple of ZJ_WIN_WORDS) into this lane's column,
+// byte-swapped to MSB-first order, with two words of look-ahead and one spare slot behind them.
+__device__ __forceinline__ void zj_stage_window(const uint32_t *stream, uint32_t w0, uint32_t *col)
 {
     const uint4 *src = reinterpret_cast<const uint4 *>(stream + w0);
     const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
     const uint2 e = *reinterpret_cast<const uint2 *>(stream + w0 + 16);
-    col[0 * 64] = taken > 0u ? 0u : a.x; col[1 * 64] = taken > 1u ? 0u : a.y; col[2 * 64] = a.z; col[3 * 64] = a.w;
-    col[4 * 64] = b.x; col[5 * 64] = b.y; col[6 * 64] = b.z; col[7 * 64] = b.w;
-    col[8 * 64] = c.x; col[9 * 64] = c.y; col[10 * 64] = c.z; col[11 * 64] = c.w;
-    col[12 * 64] = d.x; col[13 * 64] = d.y; col[14 * 64] = d.z; col[15 * 64] = d.w;
-    col[16 * 64] = e.x; col[17 * 64] = e.y;
+#define ZJ_SW(x) __builtin_bswap32(x)
+    col[0 * 64] = ZJ_SW(a.x); col[1 * 64] = ZJ_SW(a.y); col[2 * 64] = ZJ_SW(a.z); col[3 * 64] = ZJ_SW(a.w);
+    col[4 * 64] = ZJ_SW(b.x); col[5 * 64] = ZJ_SW(b.y); col[6 * 64] = ZJ_SW(b.z); col[7 * 64] = ZJ_SW(b.w);
+    col[8 * 64] = ZJ_SW(c.x); col[9 * 64] = ZJ_SW(c.y); col[10 * 64] = ZJ_SW(c.z); col[11 * 64] = ZJ_SW(c.w);
+    col[12 * 64] = ZJ_SW(d.x); col[13 * 64] = ZJ_SW(d.y); col[14 * 64] = ZJ_SW(d.z); col[15 * 64] = ZJ_SW(d.w);
+    col[16 * 64] = ZJ_SW(e.x); col[17 * 64] = ZJ_SW(e.y);
+#undef ZJ_SW
 }
 
 // One window for the lanes of a wavefront that have `run` set: stage window `win` (index inside the
@@ -168,13 +177,15 @@ __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *str
 {
     uint32_t n = 0;
     if (run) {
-        bits.wbase = win * ZJ_WIN_WORDS;
-        zj_stage_window(stream, win * ZJ_WIN_WORDS, col, primed ? bits.widx - bits.wbase : 0u);
-        if (!primed) { bits.init(st.p); primed = true; }
+        const uint32_t wbase = win * ZJ_WIN_WORDS;
+        zj_stage_window(stream, wbase, col);
+        if (!primed) { bits.init(col, wbase, st.p); primed = true; }
+        else bits.rebase(col, wbase, st.p);
         const uint32_t wend = (win + 1u) * ZJ_WIN_BITS;
         zj_decode_run<ZjBitsLds, ZjBitsLds>(bits, lut, canon, selw, bpm, st, wend < end ? wend : end, bits);
-        // slots the reader has not reached (the stream ended inside the window) still hold stream words
-        const uint32_t taken = bits.widx - bits.wbase;
+        // slots up to the reader's current word hold bitmap words, the ones behind it still stream words
+        bits.slot[0] = bits.bm;
+        const uint32_t taken = bits.words_done(col) + 1u;
         uint32_t w[ZJ_WIN_WORDS];
 #pragma unroll
         for (int i = 0; i < ZJ_WIN_WORDS; i++) {
@@ -364,7 +375,6 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
     const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
     uint32_t *bitmap = reinterpret_cast<uint32_t *>(P.bitmap + sg.out_off);
     ZjBitsLds bits;
-    bits.col = col;
     bool primed = false;
     ZjState st = {jl * SB, 0, 0};
     const bool act0 = sub_active(sg, jl, SB, pay);

@@ -188,8 +188,10 @@ __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *str
         const uint32_t taken = bits.words_done(col) + 1u;
         uint32_t w[ZJ_WIN_WORDS];
 #pragma unroll
+        for (int i = 0; i < ZJ_WIN_WORDS; i++) w[i] = reinterpret_cast<volatile uint32_t *>(col)[i * 64];
+#pragma unroll
         for (int i = 0; i < ZJ_WIN_WORDS; i++) {
-            w[i] = (uint32_t)i < taken ? col[i * 64] : 0u;
+            w[i] = (uint32_t)i < taken ? w[i] : 0u;
             n += __popc(w[i]);
         }
         uint4 *dst = reinterpret_cast<uint4 *>(bitmap + (size_t)win * ZJ_WIN_WORDS);

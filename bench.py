@@ -36,6 +36,7 @@ def parse_args():
     ap.add_argument("--subseq-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=48, help="images decoded by the CPU baseline")
+    ap.add_argument("--h2h-sample", type=int, default=512, help="images of the host-to-host (PCIe-inclusive) leg, 0 = skip")
     return ap.parse_args()
 
 
@@ -129,8 +130,10 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom)
+            try:  # PMC-derived HBM bytes per launch of the dominant kernel, valid for the profiled batch size only
+                t = json.load(open(tpath))
+                if t.get("images") == a.images and a.sampling == "420" and a.content == 0:
+                    traffic = t["kernels"].get(dom)
             except Exception:
                 traffic = None
         ms_per_step = wall / a.steps * 1e3
@@ -156,11 +159,46 @@ def main():
             result["cpu_baseline"] = cpu_baseline(files, a, threads)
     batch.close()
     ctx.close()
+    if rank == 0 and world == 1 and a.h2h_sample > 0 and not a.no_cpu_baseline:
+        del out_all, outs
+        torch.cuda.empty_cache()
+        result["host_to_host"] = host_to_host(parsed, a, dev, stride)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+
+
+def host_to_host(parsed, a, dev, stride):
+    """PCIe-inclusive rate, reported beside the device-resident figure and never as `value`: parsed images in
+    host memory -> plan + upload (zj_batch_create) -> decode -> RGB copied to pinned host memory."""
+    import torch
+    import jpeg_decoder_amd as J
+    n = min(a.h2h_sample, a.images)
+    images = [parsed[i % len(parsed)] for i in range(n)]
+    stream = torch.cuda.Stream(device=dev)
+    ctx = J.Context(dev, stream=stream.cuda_stream)
+    host = torch.empty((n, a.height, stride), dtype=torch.uint8).pin_memory()
+    out = torch.empty((n, a.height, stride), dtype=torch.uint8, device=f"cuda:{dev}")
+    outs = [out[i] for i in range(n)]
+    best = None
+    for _ in range(2):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        b = J.Batch(ctx, images, a.subseq_bits)
+        b.decode(outs)
+        st = b.finish()
+        with torch.cuda.stream(stream):
+            host.copy_(out, non_blocking=True)
+        stream.synchronize()
+        dt = time.perf_counter() - t0
+        b.close()
+        assert not st.any()
+        best = dt if best is None else min(best, dt)
+    ctx.close()
+    return {"value": round(a.width * a.height * n / best / 1e6, 1), "unit": "MP/s", "images": n,
+            "includes": "batch planning, scan upload, decode, RGB download to pinned host memory (no overlap between them)"}
 
 
 def cpu_baseline(files, a, threads):

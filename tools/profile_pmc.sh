@@ -9,7 +9,8 @@ shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
-ARGS="--images 256 --steps 1 --warmup 1 --no-cpu-baseline $*"
+IMAGES=${IMAGES:-256}
+ARGS="--images $IMAGES --steps 1 --warmup 1 --no-cpu-baseline $*"
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -3 "$OUT/trace.log"; exit 1; }
 pass() {
@@ -22,3 +23,4 @@ pass sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS 
 pass fetch FETCH_SIZE GRBM_GUI_ACTIVE || exit 1
 pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum || exit 1
 python3 "$ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/summary.json" && echo "summary written: $OUT/summary.json"
+python3 "$ROOT/tools/pmc_traffic.py" "$OUT/summary.json" "$IMAGES" > "$OUT/traffic.json" && echo "traffic written: $OUT/traffic.json"

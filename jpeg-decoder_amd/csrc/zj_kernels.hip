@@ -632,39 +632,56 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
     __syncthreads();
 
     const uint32_t nl = im.hs * im.vs, bpm = im.bpm;
+    const uint32_t shl = nl == 4u ? 2u : (nl == 2u ? 1u : 0u);     // log2 of the luma blocks per MCU
     const uint32_t M = nl == 1u ? 64u : 32u;                       // MCUs per wavefront
     const uint32_t m0 = ((blockIdx.x - im.first_k1w) * 4u + wave) * M; // first MCU of this wavefront
     const uint32_t nmcu = im.nblocks / bpm;
     if (m0 >= nmcu) return; // wave-uniform
-    const uint32_t rounds_l = M * nl / 64u, rounds = rounds_l + M * 2u / 64u;
+    const uint32_t rounds_l = (M << shl) / 64u, rounds = rounds_l + M * 2u / 64u;
     uint32_t *row32 = &tile[wave][lane * 33u];
     uint32_t status = 0;
+    // images without restart markers have one segment: its description is the same for every block
+    const bool oneseg = im.ri_blocks == 0u;
+    uint32_t seg = im.first_seg, found = 0, pay = 0;
+    const uint32_t *stream = nullptr;
+    if (oneseg) {
+        found = min(P.seg_found[seg], P.segs[seg].nblocks);
+        pay = P.seg_payload_bits[seg];
+        stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[seg].out_off);
+    }
     for (uint32_t r = 0; r < rounds; r++) {
 #pragma unroll
         for (int i = 0; i < 33; i++) row32[i] = 0;
         // block of this lane in this round
         const bool luma = r < rounds_l;
-        const uint32_t qi = (luma ? r : r - rounds_l) * 64u + lane;
-        const uint32_t per = luma ? nl : 2u;
-        const uint32_t mcu = m0 + qi / per;
-        const uint32_t kb = (luma ? 0u : nl) + qi % per;
+        const uint32_t sh = luma ? shl : 1u;
+        const uint32_t qbase = (luma ? r : r - rounds_l) * 64u;
+        const uint32_t qi = qbase + lane;
+        const uint32_t mcu = m0 + (qi >> sh);
+        const uint32_t kb = (luma ? 0u : nl) + (qi & ((1u << sh) - 1u));
         const uint32_t gl = mcu * bpm + kb; // block index inside the image
         if (mcu < nmcu) {
             const uint32_t g = im.first_block + gl;
-            const uint32_t segi = im.ri_blocks ? gl / im.ri_blocks : 0u;
-            const uint32_t seg = im.first_seg + segi;
-            const uint32_t gs = gl - segi * im.ri_blocks;
+            uint32_t gs = gl;
+            if (!oneseg) {
+                const uint32_t segi = gl / im.ri_blocks;
+                seg = im.first_seg + segi;
+                gs = gl - segi * im.ri_blocks;
+                found = min(P.seg_found[seg], P.segs[seg].nblocks);
+                pay = P.seg_payload_bits[seg];
+                stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[seg].out_off);
+            }
             uint32_t st;
-            if (gs < P.seg_found[seg]) {
-                const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[seg].out_off);
+            if (gs < found) {
+                const uint32_t p0 = P.blockpos[g];
+                const uint32_t pnext = gs + 1u < found ? P.blockpos[g + 1u] : 0xFFFFFFFFu;
                 uint32_t pend;
-                st = zj_decode_block(stream, lut, canon, (im.dcsel >> kb) & 1u, (im.acsel >> kb) & 1u, P.blockpos[g],
-                                     P.dcabs[g], reinterpret_cast<int16_t *>(row32), &pend);
-                if (pend > P.seg_payload_bits[seg]) st |= 4u; // ZJ_ST_TRUNCATED
+                st = zj_decode_block(stream, lut, canon, (im.dcsel >> kb) & 1u, (im.acsel >> kb) & 1u, p0, P.dcabs[g],
+                                     reinterpret_cast<int16_t *>(row32), &pend);
+                if (pend > pay) st |= 4u; // ZJ_ST_TRUNCATED
                 // a cleanly decoded block ends where the next one begins; if it does not, the position
                 // list does not describe the sequential decode
-                if (st == 0u && gs + 1u < min(P.seg_found[seg], P.segs[seg].nblocks) && P.blockpos[g + 1u] != pend)
-                    atomicOr(&P.flags[1], 1u);
+                if (st == 0u && pnext != 0xFFFFFFFFu && pnext != pend) atomicOr(&P.flags[1], 1u);
             } else {
                 st = 4u;
             }
@@ -676,10 +693,10 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
         for (uint32_t it = 0; it < 8u; it++) {
             const uint32_t q = it * 64u + lane;
             const uint32_t rl = q >> 3, part = q & 7u;
-            const uint32_t qj = (luma ? r : r - rounds_l) * 64u + rl;
-            const uint32_t mj = m0 + qj / per;
+            const uint32_t qj = qbase + rl;
+            const uint32_t mj = m0 + (qj >> sh);
             if (mj < nmcu) {
-                const uint32_t gj = im.first_block + mj * bpm + (luma ? 0u : nl) + qj % per;
+                const uint32_t gj = im.first_block + mj * bpm + (luma ? 0u : nl) + (qj & ((1u << sh) - 1u));
                 const uint32_t *src = &tile[wave][rl * 33u + part * 4u];
                 *reinterpret_cast<uint4 *>(P.qcoef + (size_t)gj * 64u + part * 8u) = make_uint4(src[0], src[1], src[2], src[3]);
             }

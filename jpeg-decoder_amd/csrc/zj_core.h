@@ -242,6 +242,21 @@ struct ZjBits4 {
         widx++;
         return zj_bswap32(w);
     }
+    // the same with the four pieces that hold bit `bitpos` and the 48 bytes behind it already loaded
+    ZJ_HD void init_loaded(const uint32_t *b, uint32_t bitpos, const ZjU4 &c0, const ZjU4 &c1, const ZjU4 &c2, const ZjU4 &c3)
+    {
+        base = reinterpret_cast<const ZjU4 *>(b);
+        const uint32_t word = bitpos >> 5;
+        cur = c0; n1 = c1; n2 = c2; n3 = c3;
+        left = 16;
+        if (word & 1u) { cur.x = cur.y; cur.y = cur.z; cur.z = cur.w; left -= 1; }
+        if (word & 2u) { cur.x = cur.z; cur.y = cur.w; left -= 2; }
+        widx = word;
+        uint64_t w0 = take_first(), w1 = take();
+        const uint32_t sh = bitpos & 31u;
+        buf = ((w0 << 32) | w1) << sh;
+        cnt = 64 - (int32_t)sh;
+    }
     ZJ_HD void init(const uint32_t *b, uint32_t bitpos)
     {
         base = reinterpret_cast<const ZjU4 *>(b);
@@ -452,11 +467,21 @@ ZJ_HD uint32_t zj_walk_window_direct(const uint32_t *stream, uint32_t *bitmap, c
 // from the prefix scan; only its bits are skipped here.  The AC loop is written with selects instead
 // of branches: the lanes of a wavefront are at different points of different blocks.  Returns status
 // bits and the bit position behind the block.
+ZJ_HD uint32_t zj_decode_block_on(ZjBits4 &bits, const uint16_t *lut, const ZjCanon *canon, uint32_t tdc, uint32_t tac,
+                                  uint32_t p0, int16_t dc, int16_t *row, uint32_t *pend);
+
 ZJ_HD uint32_t zj_decode_block(const uint32_t *stream, const uint16_t *lut, const ZjCanon *canon, uint32_t tdc,
                                uint32_t tac, uint32_t p0, int16_t dc, int16_t *row, uint32_t *pend)
 {
     ZjBits4 bits;
     bits.init(stream, p0);
+    return zj_decode_block_on(bits, lut, canon, tdc, tac, p0, dc, row, pend);
+}
+
+// The same on a reader that is already positioned at p0.
+ZJ_HD uint32_t zj_decode_block_on(ZjBits4 &bits, const uint16_t *lut, const ZjCanon *canon, uint32_t tdc, uint32_t tac,
+                                  uint32_t p0, int16_t dc, int16_t *row, uint32_t *pend)
+{
     uint32_t p = p0, status = 0;
     {
         uint32_t top = bits.top32();

@@ -649,44 +649,86 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
         pay = P.seg_payload_bits[seg];
         stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[seg].out_off);
     }
+    // What a lane needs to know about its block of a round, and the first 64 bytes of the block's bits.
+    // Both are fetched ahead of the round that uses them -- the description two rounds ahead, the bits
+    // one round ahead (their address comes out of the description) -- so that a round starts decoding
+    // at once instead of waiting for two dependent trips to memory.
+    struct Desc {
+        uint32_t p0, pnext, pay, kb;
+        const uint32_t *stream;
+        int16_t dc;
+        bool valid, have; // the block exists / its position is known
+    };
+    auto describe = [&](uint32_t r) -> Desc {
+        Desc d;
+        d.valid = false; d.have = false; d.p0 = 0; d.pnext = 0xFFFFFFFFu; d.pay = 0; d.kb = 0; d.stream = nullptr; d.dc = 0;
+        if (r >= rounds) return d;
+        const bool luma = r < rounds_l;
+        const uint32_t sh = luma ? shl : 1u;
+        const uint32_t qi = (luma ? r : r - rounds_l) * 64u + lane;
+        const uint32_t mcu = m0 + (qi >> sh);
+        d.kb = (luma ? 0u : nl) + (qi & ((1u << sh) - 1u));
+        if (mcu >= nmcu) return d;
+        d.valid = true;
+        const uint32_t gl = mcu * bpm + d.kb; // block index inside the image
+        const uint32_t g = im.first_block + gl;
+        uint32_t gs = gl, fnd = found;
+        d.pay = pay;
+        d.stream = stream;
+        if (!oneseg) {
+            const uint32_t segi = gl / im.ri_blocks;
+            const uint32_t sgi = im.first_seg + segi;
+            gs = gl - segi * im.ri_blocks;
+            fnd = min(P.seg_found[sgi], P.segs[sgi].nblocks);
+            d.pay = P.seg_payload_bits[sgi];
+            d.stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[sgi].out_off);
+        }
+        if (gs < fnd) {
+            d.have = true;
+            d.p0 = P.blockpos[g];
+            d.dc = P.dcabs[g];
+            if (gs + 1u < fnd) d.pnext = P.blockpos[g + 1u];
+        }
+        return d;
+    };
+    ZjU4 h0 = {0, 0, 0, 0}, h1 = h0, h2 = h0, h3 = h0; // bits of the current round's block
+    auto fetch_head = [&](const Desc &d, ZjU4 &c0, ZjU4 &c1, ZjU4 &c2, ZjU4 &c3) {
+        if (d.have) {
+            const ZjU4 *src = reinterpret_cast<const ZjU4 *>(d.stream) + (d.p0 >> 7);
+            c0 = src[0]; c1 = src[1]; c2 = src[2]; c3 = src[3];
+        }
+    };
+    Desc cur = describe(0);
+    fetch_head(cur, h0, h1, h2, h3);
+    Desc nxt = describe(1);
     for (uint32_t r = 0; r < rounds; r++) {
 #pragma unroll
         for (int i = 0; i < 33; i++) row32[i] = 0;
-        // block of this lane in this round
         const bool luma = r < rounds_l;
         const uint32_t sh = luma ? shl : 1u;
         const uint32_t qbase = (luma ? r : r - rounds_l) * 64u;
-        const uint32_t qi = qbase + lane;
-        const uint32_t mcu = m0 + (qi >> sh);
-        const uint32_t kb = (luma ? 0u : nl) + (qi & ((1u << sh) - 1u));
-        const uint32_t gl = mcu * bpm + kb; // block index inside the image
-        if (mcu < nmcu) {
-            const uint32_t g = im.first_block + gl;
-            uint32_t gs = gl;
-            if (!oneseg) {
-                const uint32_t segi = gl / im.ri_blocks;
-                seg = im.first_seg + segi;
-                gs = gl - segi * im.ri_blocks;
-                found = min(P.seg_found[seg], P.segs[seg].nblocks);
-                pay = P.seg_payload_bits[seg];
-                stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[seg].out_off);
-            }
+        ZjU4 n0 = {0, 0, 0, 0}, n1 = n0, n2 = n0, n3 = n0;
+        fetch_head(nxt, n0, n1, n2, n3);
+        const Desc nn = describe(r + 2u);
+        if (cur.valid) {
             uint32_t st;
-            if (gs < found) {
-                const uint32_t p0 = P.blockpos[g];
-                const uint32_t pnext = gs + 1u < found ? P.blockpos[g + 1u] : 0xFFFFFFFFu;
+            if (cur.have) {
+                ZjBits4 bits;
+                bits.init_loaded(cur.stream, cur.p0, h0, h1, h2, h3);
                 uint32_t pend;
-                st = zj_decode_block(stream, lut, canon, (im.dcsel >> kb) & 1u, (im.acsel >> kb) & 1u, p0, P.dcabs[g],
-                                     reinterpret_cast<int16_t *>(row32), &pend);
-                if (pend > pay) st |= 4u; // ZJ_ST_TRUNCATED
+                st = zj_decode_block_on(bits, lut, canon, (im.dcsel >> cur.kb) & 1u, (im.acsel >> cur.kb) & 1u, cur.p0, cur.dc,
+                                        reinterpret_cast<int16_t *>(row32), &pend);
+                if (pend > cur.pay) st |= 4u; // ZJ_ST_TRUNCATED
                 // a cleanly decoded block ends where the next one begins; if it does not, the position
                 // list does not describe the sequential decode
-                if (st == 0u && pnext != 0xFFFFFFFFu && pnext != pend) atomicOr(&P.flags[1], 1u);
+                if (st == 0u && cur.pnext != 0xFFFFFFFFu && cur.pnext != pend) atomicOr(&P.flags[1], 1u);
             } else {
                 st = 4u;
             }
             status |= st;
         }
+        cur = nxt; nxt = nn;
+        h0 = n0; h1 = n1; h2 = n2; h3 = n3;
         zj_wave_lds_sync();
         // store: piece q = (row q / 8, sixteen bytes q % 8); the row's block is recomputed from its lane
 #pragma unroll

@@ -333,6 +333,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.bitmap = dev_alloc<uint8_t>(b, ust_total + 1040, true);
     P.blockpos = dev_alloc<uint32_t>(b, nblk_total, true);
     P.dcabs = dev_alloc<int16_t>(b, nblk_total, true);
+    P.dcbits = dev_alloc<uint8_t>(b, nblk_total, true);
     P.qcoef = dev_alloc<int16_t>(b, nblk_total * 64, false);
     P.status = dev_alloc<uint32_t>(b, n, true);
     P.flags = dev_alloc<uint32_t>(b, 4, true);
@@ -342,7 +343,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.rgb_stride = b->d_stride;
     P.nchunks = (uint32_t)chunk_seg.size();
     ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.wluts && P.canons && P.qts && raw && P.ust &&
-         P.seg_payload_bits && P.seg_found && P.winfo && P.wbase && P.bitmap && P.ptile_seg && P.tile_seg && P.tile_status && P.blockpos && P.dcabs && P.qcoef && P.status &&
+         P.seg_payload_bits && P.seg_found && P.winfo && P.wbase && P.bitmap && P.ptile_seg && P.tile_seg && P.tile_status && P.blockpos && P.dcabs && P.dcbits && P.qcoef && P.status &&
          P.flags && b->d_rgb && b->d_stride;
     if (ok) ok = hip_ok(ctx, hipHostMalloc((void **)&b->h_rgb, (n ? n : 1) * sizeof(uint8_t *), hipHostMallocDefault), "hipHostMalloc") &&
                  hip_ok(ctx, hipHostMalloc((void **)&b->h_stride, (n ? n : 1) * sizeof(size_t), hipHostMallocDefault), "hipHostMalloc") &&

@@ -349,7 +349,9 @@ ZJ_HD int32_t zj_extend(uint32_t nbits, uint32_t v)
 
 // DC difference of the block whose DC symbol starts at bit `p` (src/decoder.rs:194-199 without the
 // predictor): one table lookup and the EXTEND of the bits behind the code.
-ZJ_HD int32_t zj_dc_diff(const uint32_t *stream, const uint16_t *dctbl, const ZjCanon *canon, uint32_t p)
+// *nbits receives the bits the DC symbol and its value take, or ZJ_DC_BAD if the bits are no code.
+#define ZJ_DC_BAD 0xFFu
+ZJ_HD int32_t zj_dc_diff(const uint32_t *stream, const uint16_t *dctbl, const ZjCanon *canon, uint32_t p, uint32_t *nbits)
 {
     const uint32_t w = p >> 5, sh = p & 31u;
     const uint64_t two = ((uint64_t)zj_bswap32(stream[w]) << 32) | zj_bswap32(stream[w + 1]);
@@ -357,7 +359,8 @@ ZJ_HD int32_t zj_dc_diff(const uint32_t *stream, const uint16_t *dctbl, const Zj
     const uint32_t e = zj_lookup(dctbl, canon, top);
     const uint32_t len = (e >> 8) & 31u;
     uint32_t s = e & 255u;
-    if (len == 0 || s > 16u) return 0; // not a code: the write pass reports it
+    if (len == 0 || s > 16u) { *nbits = ZJ_DC_BAD; return 0; } // not a code: the write pass reports it
+    *nbits = len + s;
     const uint32_t v = s ? ((top << len) >> (32 - s)) : 0u;
     return zj_extend(s, v);
 }

@@ -35,6 +35,7 @@ struct ZjParams {
     uint32_t *tile_ticket;      // = (uint32_t *)&tile_status[ntiles]
     uint32_t *blockpos;         // [block] bit position of the block in its segment's stream
     int16_t *dcabs;             // [block] DC value after prediction
+    uint8_t *dcbits;            // [block] bits of the DC symbol and its value (ZJ_DC_BAD: no code)
     int16_t *qcoef;             // [block][64] zig-zag, quantised: the stage seam
     const uint16_t *luts;       // [table set][ZJ_SET_ENTRIES]
     const uint16_t *wluts;      // the same sets as walk entries

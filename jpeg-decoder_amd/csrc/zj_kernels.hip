@@ -554,13 +554,15 @@ __global__ __launch_bounds__(256) void zj_k1c_dcdiff(ZjParams P)
     const uint32_t seg = im.first_seg + segi;
     const uint32_t gs = gl - segi * im.ri_blocks;
     int32_t d = 0;
+    uint32_t nbits = ZJ_DC_BAD;
     if (gs < P.seg_found[seg]) {
         const uint32_t t = (im.dcsel >> (gs % im.bpm)) & 1u;
         const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[seg].out_off);
         d = zj_dc_diff(stream, P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES + t * ZJ_TBL_ENTRIES,
-                       P.canons + (size_t)im.lut_set * 4u + t, P.blockpos[g]);
+                       P.canons + (size_t)im.lut_set * 4u + t, P.blockpos[g], &nbits);
     }
     P.dcabs[g] = (int16_t)d; // turned into the predicted value in place by the scan
+    P.dcbits[g] = (uint8_t)nbits;
 }
 
 // ---------------------------------------------------------------------------------- k1d: DC scan
@@ -619,16 +621,27 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan(ZjParams P)
 // decodes its block into a private 132-byte row of an LDS tile (a row pitch of 33 words keeps lanes
 // on distinct banks while they write the same zig-zag index); then the wavefront stores the 64 rows,
 // eight lanes per block, one full 128-byte line per block.
+// The block's bits are staged in a private LDS column of 16 words (the 64 bytes that hold the block's
+// first bit, fetched a round ahead), read with the same branch-free two-word reader as the sync pass;
+// a block that outgrows its column waits for the others and is restaged.  The DC symbol is not decoded
+// again: its length comes from the DC pass.
 // MCUs per wavefront: 64 for 4:4:4 (1 luma + 2 chroma rounds), 32 otherwise.
+#define ZJ_K1W_SLOTS 16u
+
 __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
+    __shared__ __attribute__((aligned(16))) uint16_t lut[2 * ZJ_TBL_ENTRIES]; // the two AC tables
     __shared__ uint32_t tile[4][64 * 33];
+    __shared__ uint32_t scol[4][ZJ_K1W_SLOTS * 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t ii = P.k1w_img[blockIdx.x];
     const ZjImgDev &im = P.imgs[ii];
-    load_lut_to_lds(lut, P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
-    const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
+    {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES + 2u * ZJ_TBL_ENTRIES);
+        uint4 *d4 = reinterpret_cast<uint4 *>(lut);
+        for (uint32_t i = threadIdx.x; i < 2u * ZJ_TBL_ENTRIES * 2u / 16u; i += 256u) d4[i] = s4[i];
+    }
+    const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u + 2u;
     __syncthreads();
 
     const uint32_t nl = im.hs * im.vs, bpm = im.bpm;
@@ -639,6 +652,8 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
     if (m0 >= nmcu) return; // wave-uniform
     const uint32_t rounds_l = (M << shl) / 64u, rounds = rounds_l + M * 2u / 64u;
     uint32_t *row32 = &tile[wave][lane * 33u];
+    int16_t *row = reinterpret_cast<int16_t *>(row32);
+    uint32_t *col = &scol[wave][lane];
     uint32_t status = 0;
     // images without restart markers have one segment: its description is the same for every block
     const bool oneseg = im.ri_blocks == 0u;
@@ -654,7 +669,7 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
     // one round ahead (their address comes out of the description) -- so that a round starts decoding
     // at once instead of waiting for two dependent trips to memory.
     struct Desc {
-        uint32_t p0, pnext, pay, kb;
+        uint32_t p0, pnext, pay, kb, dcbits;
         const uint32_t *stream;
         int16_t dc;
         bool valid, have; // the block exists / its position is known
@@ -662,6 +677,7 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
     auto describe = [&](uint32_t r) -> Desc {
         Desc d;
         d.valid = false; d.have = false; d.p0 = 0; d.pnext = 0xFFFFFFFFu; d.pay = 0; d.kb = 0; d.stream = nullptr; d.dc = 0;
+        d.dcbits = ZJ_DC_BAD;
         if (r >= rounds) return d;
         const bool luma = r < rounds_l;
         const uint32_t sh = luma ? shl : 1u;
@@ -687,6 +703,7 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
             d.have = true;
             d.p0 = P.blockpos[g];
             d.dc = P.dcabs[g];
+            d.dcbits = P.dcbits[g];
             if (gs + 1u < fnd) d.pnext = P.blockpos[g + 1u];
         }
         return d;
@@ -697,6 +714,14 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
             const ZjU4 *src = reinterpret_cast<const ZjU4 *>(d.stream) + (d.p0 >> 7);
             c0 = src[0]; c1 = src[1]; c2 = src[2]; c3 = src[3];
         }
+    };
+    auto stage = [&](const ZjU4 &c0, const ZjU4 &c1, const ZjU4 &c2, const ZjU4 &c3) {
+#define ZJ_SW(x) __builtin_bswap32(x)
+        col[0 * 64] = ZJ_SW(c0.x); col[1 * 64] = ZJ_SW(c0.y); col[2 * 64] = ZJ_SW(c0.z); col[3 * 64] = ZJ_SW(c0.w);
+        col[4 * 64] = ZJ_SW(c1.x); col[5 * 64] = ZJ_SW(c1.y); col[6 * 64] = ZJ_SW(c1.z); col[7 * 64] = ZJ_SW(c1.w);
+        col[8 * 64] = ZJ_SW(c2.x); col[9 * 64] = ZJ_SW(c2.y); col[10 * 64] = ZJ_SW(c2.z); col[11 * 64] = ZJ_SW(c2.w);
+        col[12 * 64] = ZJ_SW(c3.x); col[13 * 64] = ZJ_SW(c3.y); col[14 * 64] = ZJ_SW(c3.z); col[15 * 64] = ZJ_SW(c3.w);
+#undef ZJ_SW
     };
     Desc cur = describe(0);
     fetch_head(cur, h0, h1, h2, h3);
@@ -710,21 +735,62 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
         ZjU4 n0 = {0, 0, 0, 0}, n1 = n0, n2 = n0, n3 = n0;
         fetch_head(nxt, n0, n1, n2, n3);
         const Desc nn = describe(r + 2u);
-        if (cur.valid) {
-            uint32_t st;
-            if (cur.have) {
-                ZjBits4 bits;
-                bits.init_loaded(cur.stream, cur.p0, h0, h1, h2, h3);
-                uint32_t pend;
-                st = zj_decode_block_on(bits, lut, canon, (im.dcsel >> cur.kb) & 1u, (im.acsel >> cur.kb) & 1u, cur.p0, cur.dc,
-                                        reinterpret_cast<int16_t *>(row32), &pend);
-                if (pend > cur.pay) st |= 4u; // ZJ_ST_TRUNCATED
-                // a cleanly decoded block ends where the next one begins; if it does not, the position
-                // list does not describe the sequential decode
-                if (st == 0u && cur.pnext != 0xFFFFFFFFu && cur.pnext != pend) atomicOr(&P.flags[1], 1u);
-            } else {
-                st = 4u;
+
+        // ---- this round's block (src/decoder.rs:186-235; the DC value comes from the prefix scan)
+        uint32_t p = cur.p0 + cur.dcbits, z = 1, e = 0x0100u, z2 = 0;
+        bool live = cur.valid && cur.have && cur.dcbits != ZJ_DC_BAD; // still has symbols to decode
+        if (cur.valid && !live) status |= cur.have ? 1u : 4u;            // no DC code / no position: bad code / truncated
+        if (live) {
+            row[0] = cur.dc;
+            stage(h0, h1, h2, h3);
+        }
+        uint32_t wa = (cur.p0 >> 7) << 2; // stream word held in slot 0 of the column
+        const uint16_t *ac = lut + ((im.acsel >> cur.kb) & 1u) * ZJ_TBL_ENTRIES;
+        const ZjCanon *cac = canon + ((im.acsel >> cur.kb) & 1u);
+        for (;;) {
+            if (live) {
+                // position the reader: the column holds the 16 words from word wa on
+                uint32_t *slot = col + ((p >> 5) - wa) * 64u;
+                uint32_t w0 = slot[0], w1 = slot[64], o = p & 31u;
+                uint32_t *const last = col + (ZJ_K1W_SLOTS - 3u) * 64u; // the reader needs two words behind its own
+                for (;;) {
+                    const uint32_t top = (uint32_t)(((((uint64_t)w0 << 32) | w1) << o) >> 32);
+                    const uint32_t wn = slot[128];
+                    e = zj_lookup(ac, cac, top);
+                    const uint32_t len = (e >> 8) & 31u, sz = e & 15u;
+                    z2 = z + ((e >> 4) & 15u);                 // src/decoder.rs:225
+                    const bool eob = (e & 255u) == 0;          // :212 (a pattern that is no code reads as 0 too)
+                    const uint32_t at = z2 < 64u ? z2 : 64u;   // :228 would index out of bounds at 64 and above
+                    row[eob ? 64u : at] = (int16_t)zj_value_ac(top << len, sz);
+                    const uint32_t adv = len + sz;
+                    p += adv;
+                    if (eob || z2 >= 63u) { live = false; break; } // :212, :232 (and the overflow case)
+                    z = z2 + 1u;                               // :230
+                    o += adv;
+                    const bool step = o >= 32u;
+                    w0 = step ? w1 : w0;
+                    w1 = step ? wn : w1;
+                    slot += step ? 64 : 0;
+                    o &= 31u;
+                    if (slot > last) break; // out of staged bits: wait for the others, then restage
+                }
             }
+            if (!__any(live)) break;
+            if (live) {
+                const ZjU4 *src = reinterpret_cast<const ZjU4 *>(cur.stream) + (p >> 7);
+                const ZjU4 c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
+                stage(c0, c1, c2, c3);
+                wa = (p >> 7) << 2;
+            }
+        }
+        if (cur.valid && cur.have && cur.dcbits != ZJ_DC_BAD) {
+            uint32_t st = 0;
+            if (((e >> 8) & 31u) == 0) st = 1u;                        // ZJ_ST_BAD_CODE
+            else if ((e & 255u) != 0 && z2 >= 64u) st = 2u;            // ZJ_ST_COEF_OVERFLOW
+            if (p > cur.pay) st |= 4u;                                 // ZJ_ST_TRUNCATED
+            // a cleanly decoded block ends where the next one begins; if it does not, the position
+            // list does not describe the sequential decode
+            if (st == 0u && cur.pnext != 0xFFFFFFFFu && cur.pnext != p) atomicOr(&P.flags[1], 1u);
             status |= st;
         }
         cur = nxt; nxt = nn;

@@ -171,7 +171,8 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
             uint32_t c = (compsel >> (2 * (g % bpm))) & 3;
             if (g < found) {
                 uint32_t t = (sel.dcsel >> (g % bpm)) & 1;
-                run[c] += (uint32_t)zj_dc_diff(stream, &lut[t * ZJ_TBL_ENTRIES], &canon[t], blockpos[g]);
+                uint32_t nbits;
+                run[c] += (uint32_t)zj_dc_diff(stream, &lut[t * ZJ_TBL_ENTRIES], &canon[t], blockpos[g], &nbits);
             }
             dcabs[g] = (int16_t)run[c];
         }

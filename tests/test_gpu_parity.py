@@ -109,8 +109,21 @@ def test_content_classes_1080p(ctx):
     blocks per subsequence, noise streams few)."""
     for (hs, vs, cls, seed) in [(2, 2, 0, 1), (2, 2, 1, 2), (2, 2, 2, 3), (1, 1, 0, 4)]:
         data = synth.encode(1920, 1080, hs, vs, 90, cls, seed)
-        rgb, st, coef = J.decode_images(ctx, [J.ParsedImage(data)], subseq_bits=2048, want_coef=True)
-        assert_same(data, rgb[0], st[0], coef[0])
+        for sb in (2048, 65536):
+            rgb, st, coef = J.decode_images(ctx, [J.ParsedImage(data)], subseq_bits=sb, want_coef=True)
+            assert_same(data, rgb[0], st[0], coef[0])
+
+
+def test_long_blocks_and_many_segments(ctx):
+    """Blocks of many hundred bits (white noise at quality 100: the write pass has to restage a block's
+    bits), and an image cut into more than a thousand restart segments, each decoded at the default
+    subsequence size and with long subsequences."""
+    cases = [synth.encode(512, 512, 2, 2, 100, 2, 31), synth.encode(256, 256, 1, 1, 100, 2, 32),
+             synth.encode(1024, 1024, 2, 2, 90, 0, 33, 4), synth.encode(640, 480, 2, 1, 95, 2, 34, 3)]
+    for data in cases:
+        for sb in (0, 32768):
+            rgb, st, coef = J.decode_images(ctx, [J.ParsedImage(data)], subseq_bits=sb, want_coef=True)
+            assert_same(data, rgb[0], st[0], coef[0])
 
 
 def test_batch_of_1080p_is_deterministic_and_uniform(ctx):

@@ -35,6 +35,9 @@ def parse_args():
     ap.add_argument("--content", type=int, default=0, help="0 natural, 1 smooth, 2 white noise")
     ap.add_argument("--subseq-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --one-device: rehearsal of the multi-rank path on a box with a single GPU")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     ap.add_argument("--cpu-sample", type=int, default=48, help="images decoded by the CPU baseline")
     ap.add_argument("--h2h-sample", type=int, default=512, help="images of the host-to-host (PCIe-inclusive) leg, 0 = skip")
     return ap.parse_args()
@@ -52,11 +55,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = local_rank if (world > 1 and not a.one_device) else 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    dev = local_rank if world > 1 else 0
+        torch.cuda.set_device(dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev}"))
+        else:
+            dist.init_process_group("gloo")
     torch.cuda.set_device(dev)
 
     hs, vs = {"420": (2, 2), "444": (1, 1), "422": (2, 1), "440": (1, 2)}[a.sampling]
@@ -98,7 +104,7 @@ def main():
     wall = t1 - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{dev}")
+        t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{dev}" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     st = batch.finish()

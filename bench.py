@@ -39,7 +39,9 @@ def parse_args():
                     help="gloo + --one-device: rehearsal of the multi-rank path on a box with a single GPU")
     ap.add_argument("--one-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
     ap.add_argument("--cpu-sample", type=int, default=48, help="images decoded by the CPU baseline")
-    ap.add_argument("--h2h-sample", type=int, default=512, help="images of the host-to-host (PCIe-inclusive) leg, 0 = skip")
+    ap.add_argument("--h2h-sample", type=int, default=0,
+                    help="images of the optional host-to-host (PCIe-inclusive) leg, e.g. 512; 0 = skip (default, so that "
+                         "every kernel launch of a default run has the benchmark's size)")
     return ap.parse_args()
 
 

@@ -135,9 +135,12 @@ zj_ctx *zj_create(int device, void *stream);
 void zj_destroy(zj_ctx *ctx);
 const char *zj_last_error(zj_ctx *ctx);
 
-/* Tuning knob: bits per bitstream subsequence handed to one lane of the Huffman stage (a power of
- * two, 512..8192; 0 = default). */
+/* Tuning knob: bits per bitstream subsequence handed to one lane of the Huffman stage
+ * (512..1048576, rounded per segment to whole 512-bit windows; 0 = chosen from the batch size). */
 #define ZJ_FLAG_SUBSEQ_BITS(b) ((uint32_t)(b))
+/* Testing aid: build the lookup tables without their second level, so that every code longer than the
+ * first level goes through the canonical search (the path that otherwise only unusual tables reach). */
+#define ZJ_FLAG_NO_SECOND_LEVEL 0x1000000u
 
 /* Plan a batch: validates the images, builds the device tables, uploads the scans, allocates all
  * scratch and the coefficient arena.  Everything the decode call needs is resident in HBM when

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libzj.so")
 ZJ_OK, ZJ_E_INVALID, ZJ_E_FORMAT, ZJ_E_UNSUPPORTED, ZJ_E_DEVICE, ZJ_E_NOMEM, ZJ_E_IO = 0, -1, -2, -3, -4, -5, -6
 ZJ_ST_BAD_CODE, ZJ_ST_COEF_OVERFLOW, ZJ_ST_TRUNCATED, ZJ_ST_UNSUPPORTED = 1, 2, 4, 8
 ZJ_MEM_HOST, ZJ_MEM_DEVICE = 0, 1
+ZJ_FLAG_NO_SECOND_LEVEL = 0x1000000
 ZJ_NUM_KERNELS = 9
 
 

@@ -136,6 +136,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     memset(&b->P, 0, sizeof b->P);
     memset(&b->L, 0, sizeof b->L);
 
+    const uint32_t l2_cap = (flags & ZJ_FLAG_NO_SECOND_LEVEL) ? 0u : ZJ_L2_SIZE;
     uint32_t subbits = flags & 0xFFFFFFu;
     if (subbits == 0) {
         // Enough subsequences to give every SIMD of the GPU a few wavefronts, and no more: the longer a
@@ -203,13 +204,18 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
                 bool ok = true;
                 for (int t = 0; t < 4; t++) {
                     uint16_t *tbl = &luts[(size_t)id * ZJ_SET_ENTRIES + (size_t)t * ZJ_TBL_ENTRIES];
-                    if (t4[t]) ok = zj_build_table(t4[t], tbl, &canons[(size_t)id * 4 + t]) && ok;
+                    if (t4[t]) ok = zj_build_table(t4[t], tbl, &canons[(size_t)id * 4 + t], l2_cap) && ok;
                     else { memset(tbl, 0, sizeof(uint16_t) * ZJ_TBL_ENTRIES); memset(&canons[(size_t)id * 4 + t], 0, sizeof(ZjCanon)); }
                 }
                 it = lut_ids.emplace(key, ok ? id : ZJ_NONE).first;
             }
             if (it->second == ZJ_NONE) { b->unsupported[i] = 1; d.flags = 0; d.nblocks = 0; continue; }
             d.lut_set = it->second;
+            for (uint32_t t = 0; t < 4u; t++) {
+                const uint16_t *tbl = &luts[(size_t)d.lut_set * ZJ_SET_ENTRIES + (size_t)t * ZJ_TBL_ENTRIES];
+                for (uint32_t e = 0; e < ZJ_L1_SIZE; e++)
+                    if ((tbl[e] & 0x8000u) && ((tbl[e] >> 12) & 7u) == 0) d.flags |= 2u;
+            }
         }
         for (int c = 0; c < 3; c++) {
             std::string key((const char *)im.qt[im.tq[c]], 64);

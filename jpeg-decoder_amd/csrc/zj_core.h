@@ -67,7 +67,7 @@ struct ZjImgDev {
     uint32_t qt_off[3];     // element offsets of the three components' quantisation tables (64 entries each)
     uint32_t first_strip;   // first global strip index of stage 2
     uint32_t strips_x;      // strips per MCU row
-    uint32_t flags;         // bit 0: supported
+    uint32_t flags;         // bit 0: supported, bit 1: the table set needs the canonical search for some codes
     uint32_t first_k1w;     // first workgroup of the write pass
 };
 
@@ -316,24 +316,28 @@ ZJ_HD uint32_t zj_walk_entry(uint32_t e, bool isdc)
 }
 
 // wtbl: one table of walk entries (ZJ_TBL_ENTRIES entries).
+// CANON = false is for table sets whose long codes all fit the second level (the batch planner knows):
+// the loop then contains no call.
+template <bool CANON = true>
 ZJ_HD uint32_t zj_lookup_walk(const uint16_t *wtbl, const ZjCanon *canon, uint32_t top32, bool isdc)
 {
     uint32_t e = wtbl[top32 >> (32 - ZJ_L1_BITS)];
     if (e & 0x8000u) {
         const uint32_t nb = (e >> 12) & 7u;
-        if (nb == 0) return zj_walk_entry(zj_canon_lookup(canon, top32), isdc);
+        if (CANON && nb == 0) return zj_walk_entry(zj_canon_lookup(canon, top32), isdc);
         e = wtbl[ZJ_L1_SIZE + (e & 0x1FFu) + ((top32 >> (32 - ZJ_L1_BITS - nb)) & ((1u << nb) - 1u))];
     }
     return e;
 }
 
 // tbl: one table (ZJ_TBL_ENTRIES entries).  Returns [12:8] length, [7:0] symbol; length 0 = invalid.
+template <bool CANON = true>
 ZJ_HD uint32_t zj_lookup(const uint16_t *tbl, const ZjCanon *canon, uint32_t top32)
 {
     uint32_t e = tbl[top32 >> (32 - ZJ_L1_BITS)];
     if (e & 0x8000u) {
         uint32_t nb = (e >> 12) & 7u;
-        if (nb == 0) return zj_canon_lookup(canon, top32);
+        if (CANON && nb == 0) return zj_canon_lookup(canon, top32);
         e = tbl[ZJ_L1_SIZE + (e & 0x1FFu) + ((top32 >> (32 - ZJ_L1_BITS - nb)) & ((1u << nb) - 1u))];
     }
     return e;
@@ -408,7 +412,7 @@ struct ZjEmitWords { // bitmap words addressed directly (host side, and the one-
 // Walk the symbols that START inside [st.p, stop) -- the serial loop of src/decoder.rs:194-235 seen
 // as a state machine over (bit position, block in MCU, zig-zag index) -- on a reader that is already
 // positioned at st.p.  `wlut` is a table set of walk entries.
-template <class BITS, class EMIT>
+template <class BITS, class EMIT, bool CANON = true>
 ZJ_HD void zj_decode_run(BITS &bits, const uint16_t *wlut, const ZjCanon *canon, uint32_t selw, uint32_t bpm,
                          ZjState &st, uint32_t stop, EMIT &em)
 {
@@ -419,7 +423,7 @@ ZJ_HD void zj_decode_run(BITS &bits, const uint16_t *wlut, const ZjCanon *canon,
         const uint32_t top = bits.top32();
         const bool isdc = (z == 0);
         const uint32_t t = (selw >> (2u * b + (isdc ? 0u : 16u))) & 3u;
-        const uint32_t e = zj_lookup_walk(wlut + t * ZJ_TBL_ENTRIES, canon ? canon + t : nullptr, top, t < 2u);
+        const uint32_t e = zj_lookup_walk<CANON>(wlut + t * ZJ_TBL_ENTRIES, canon ? canon + t : nullptr, top, t < 2u);
         const uint32_t tot = e & 63u;
         em.block_start(p, isdc ? 1u : 0u);
         const uint32_t z2 = z + ((e >> 6) & 127u);

@@ -230,8 +230,9 @@ extern "C" int zj_write_ppm(const char *path, uint32_t width, uint32_t height, c
 // ---------------------------------------------------------------------------------- lookup tables
 // Canonical code assignment exactly as the table walk of src/decoder.rs:523-540 (code <<= 1 per
 // length, +1 per symbol), laid out for the device as described in zj_core.h.
-bool zj_build_table(const zj_huff *h, uint16_t *tbl, ZjCanon *canon)
+bool zj_build_table(const zj_huff *h, uint16_t *tbl, ZjCanon *canon, uint32_t l2_cap)
 {
+    if (l2_cap > ZJ_L2_SIZE) l2_cap = ZJ_L2_SIZE;
     memset(tbl, 0, sizeof(uint16_t) * ZJ_TBL_ENTRIES);
     memset(canon, 0, sizeof *canon);
     if (!h) return false;
@@ -273,7 +274,7 @@ bool zj_build_table(const zj_huff *h, uint16_t *tbl, ZjCanon *canon)
             j++;
         }
         const uint32_t nb = maxlen - ZJ_L1_BITS;
-        if (used + (1u << nb) > ZJ_L2_SIZE) { overflow = true; break; }
+        if (used + (1u << nb) > l2_cap) { overflow = true; break; }
         tbl[prefix] = (uint16_t)(0x8000u | (nb << 12) | used);
         for (uint32_t t = i; t < j; t++) {
             const uint32_t extra = lens[t] - ZJ_L1_BITS;

@@ -9,5 +9,7 @@ bool zj_image_supported(const zj_image *im);
 
 // Build one device lookup table (ZJ_TBL_ENTRIES entries) and its canonical description from a DHT
 // table.  Returns false if the table is not a prefix code.
-bool zj_build_table(const zj_huff *h, uint16_t *tbl, ZjCanon *canon);
+// l2_cap: entries of the second level that may be used (ZJ_L2_SIZE; smaller values push long codes to the
+// canonical search, which is how the tests reach that path with ordinary tables)
+bool zj_build_table(const zj_huff *h, uint16_t *tbl, ZjCanon *canon, uint32_t l2_cap = ZJ_L2_SIZE);
 void zj_build_walk_table(const uint16_t *tbl, bool isdc, uint16_t *wtbl);

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "zj_core.h"
 #include "zj_dev.h"
 
@@ -170,6 +172,7 @@ __device__ __forceinline__ void zj_stage_window(const uint32_t *stream, uint32_t
 // whichever comes first, and store the window's bitmap words.  The reader carries over from window
 // to window; `primed` says whether it has been positioned yet.  Returns the number of blocks that
 // began in the window.
+template <bool CANON>
 __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *stream, uint32_t *bitmap,
                                                    const uint16_t *lut, const ZjCanon *canon, uint32_t selw,
                                                    uint32_t bpm, ZjState &st, uint32_t win, uint32_t end,
@@ -182,7 +185,7 @@ __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *str
         if (!primed) { bits.init(col, wbase, st.p); primed = true; }
         else bits.rebase(col, wbase, st.p);
         const uint32_t wend = (win + 1u) * ZJ_WIN_BITS;
-        zj_decode_run<ZjBitsLds, ZjBitsLds>(bits, lut, canon, selw, bpm, st, wend < end ? wend : end, bits);
+        zj_decode_run<ZjBitsLds, ZjBitsLds, CANON>(bits, lut, canon, selw, bpm, st, wend < end ? wend : end, bits);
         // slots up to the reader's current word hold bitmap words, the ones behind it still stream words
         bits.slot[0] = bits.bm;
         const uint32_t taken = bits.words_done(col) + 1u;
@@ -351,20 +354,13 @@ __device__ __forceinline__ uint32_t zj_load_coherent(const uint32_t *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
+template <bool CANON>
+__device__ __forceinline__ void zj_k1a_body(const ZjParams &P, const ZjImgDev &im, const uint16_t *lut, uint32_t *col, uint32_t chunk,
+                                            uint32_t lane)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
-    __shared__ uint32_t win[4][ZJ_WIN_SLOTS * 64];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t *col = &win[wave][lane];
-    const uint32_t chunk = blockIdx.x * 4u + wave;
-    const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
-    const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
-    load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
     ZjSel sel = {im.bpm, im.dcsel, im.acsel};
     const uint32_t selw = zj_selword(sel);
-    __syncthreads();
 
     const uint32_t seg = P.chunk_seg[chunk];
     if (seg == ZJ_NONE) return; // wave-uniform: a padding chunk
@@ -386,7 +382,7 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
             const bool run = act0 && st.p < end;
             if (!__any(run)) break;
             const uint32_t w = jl * NC + c;
-            const uint32_t n = zj_window_step(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
+            const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
             if (run) rec[c * 64u + lane] = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
         }
     }
@@ -401,7 +397,7 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
             const bool run = act && st.p < end;
             if (!__any(run)) break;
             const uint32_t w = q * NC + c;
-            const uint32_t n = zj_window_step(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
+            const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
             if (run) {
                 const uint32_t nw = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
                 const uint32_t old = zj_load_coherent(&rec[c * 64u + tgt]);
@@ -410,6 +406,21 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
+    __shared__ uint32_t win[4][ZJ_WIN_SLOTS * 64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t *col = &win[wave][lane];
+    const uint32_t chunk = blockIdx.x * 4u + wave;
+    const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
+    const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
+    load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
+    __syncthreads();
+    if (im.flags & 2u) zj_k1a_body<true>(P, im, lut, col, chunk, lane);
+    else zj_k1a_body<false>(P, im, lut, col, chunk, lane);
 }
 
 // ---------------------------------------------------------------------------------- k1b: fix
@@ -747,16 +758,18 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
         uint32_t wa = (cur.p0 >> 7) << 2; // stream word held in slot 0 of the column
         const uint16_t *ac = lut + ((im.acsel >> cur.kb) & 1u) * ZJ_TBL_ENTRIES;
         const ZjCanon *cac = canon + ((im.acsel >> cur.kb) & 1u);
+        const bool use_canon = (im.flags & 2u) != 0; // wave-uniform
         for (;;) {
             if (live) {
                 // position the reader: the column holds the 16 words from word wa on
                 uint32_t *slot = col + ((p >> 5) - wa) * 64u;
                 uint32_t w0 = slot[0], w1 = slot[64], o = p & 31u;
                 uint32_t *const last = col + (ZJ_K1W_SLOTS - 3u) * 64u; // the reader needs two words behind its own
-                for (;;) {
+                // one symbol per turn; the loop has a single exit so that it stays one straight run of code
+                auto turn = [&](auto with_canon) -> bool {
                     const uint32_t top = (uint32_t)(((((uint64_t)w0 << 32) | w1) << o) >> 32);
                     const uint32_t wn = slot[128];
-                    e = zj_lookup(ac, cac, top);
+                    e = zj_lookup<decltype(with_canon)::value>(ac, cac, top);
                     const uint32_t len = (e >> 8) & 31u, sz = e & 15u;
                     z2 = z + ((e >> 4) & 15u);                 // src/decoder.rs:225
                     const bool eob = (e & 255u) == 0;          // :212 (a pattern that is no code reads as 0 too)
@@ -764,7 +777,6 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
                     row[eob ? 64u : at] = (int16_t)zj_value_ac(top << len, sz);
                     const uint32_t adv = len + sz;
                     p += adv;
-                    if (eob || z2 >= 63u) { live = false; break; } // :212, :232 (and the overflow case)
                     z = z2 + 1u;                               // :230
                     o += adv;
                     const bool step = o >= 32u;
@@ -772,8 +784,11 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
                     w1 = step ? wn : w1;
                     slot += step ? 64 : 0;
                     o &= 31u;
-                    if (slot > last) break; // out of staged bits: wait for the others, then restage
-                }
+                    live = !(eob || z2 >= 63u);                // :212, :232 (and the overflow case)
+                    return live && slot <= last;               // out of staged bits: wait for the others, then restage
+                };
+                if (use_canon) { while (turn(std::true_type{})) {} }
+                else { while (turn(std::false_type{})) {} }
             }
             if (!__any(live)) break;
             if (live) {

@@ -202,3 +202,25 @@ extern "C" int zjsim_value_ac(uint32_t x, uint32_t nbits, int32_t *fast, int32_t
     *ref = zj_extend(nbits, nbits ? x >> (32 - nbits) : 0);
     return *fast == *ref;
 }
+
+// Table lookup against the canonical search on random windows, for a table built with `l2_cap`
+// second-level entries (0 pushes every long code to the canonical search).  Returns mismatches.
+extern "C" int zjsim_lookup_check(const zj_huff *h, uint32_t l2_cap, uint32_t ntests, uint64_t seed)
+{
+    std::vector<uint16_t> tbl(ZJ_TBL_ENTRIES), wtbl(ZJ_TBL_ENTRIES);
+    ZjCanon canon;
+    if (!zj_build_table(h, tbl.data(), &canon, l2_cap)) return -1;
+    int bad = 0;
+    for (int isdc = 0; isdc < 2; isdc++) {
+        zj_build_walk_table(tbl.data(), isdc != 0, wtbl.data());
+        uint64_t x = seed * 2654435761u + 12345u;
+        for (uint32_t i = 0; i < ntests; i++) {
+            x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+            const uint32_t top = (uint32_t)((x * 2685821657736338717ull) >> 32);
+            const uint32_t want = zj_canon_lookup(&canon, top);
+            if (zj_lookup(tbl.data(), &canon, top) != want) bad++;
+            if (zj_lookup_walk(wtbl.data(), &canon, top, isdc != 0) != zj_walk_entry(want, isdc != 0)) bad++;
+        }
+    }
+    return bad;
+}

@@ -52,6 +52,15 @@ def test_fixture_parity(ctx, name, subbits):
     b.close()
 
 
+def test_canonical_search_path(ctx):
+    """Tables built without their second level: every code longer than nine bits is found by the canonical
+    search inside the kernels (the path that only unusual tables reach otherwise)."""
+    for name in ("porsche.jpg", "out.jpg"):
+        data = fixture_bytes(name)
+        rgb, st, coef = J.decode_images(ctx, [J.ParsedImage(data)], subseq_bits=B.ZJ_FLAG_NO_SECOND_LEVEL | 4096, want_coef=True)
+        assert_same(data, rgb[0], st[0], coef[0])
+
+
 def test_large_fixture_parity_and_golden(ctx):
     """large.jpg (7680x4320, no restart markers): bit-exact vs the oracle and vs the committed hashes."""
     data = fixture_bytes("large.jpg")

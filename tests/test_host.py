@@ -155,3 +155,45 @@ def test_ac_value_fast_form_equals_extend():
         # edge patterns
         for x in (0, 0xFFFFFFFF, 0x80000000, 0x7FFFFFFF):
             assert S.zjsim_value_ac(x, nbits, C.byref(f), C.byref(r)), (nbits, x)
+
+
+def test_lookup_tables_equal_canonical_search():
+    """Two-level tables (and their walk-entry form) against the canonical search of src/ec.rs:30-47 on random
+    bit windows: the reference's own tables, random valid prefix codes, and tables built without a second
+    level, where every long code takes the canonical fallback."""
+    S = sim()
+    S.zjsim_lookup_check.argtypes = [C.POINTER(B.zj_huff), C.c_uint32, C.c_uint32, C.c_uint64]
+    tables = []
+    for name in ("porsche.jpg", "profile.jpg", "test-baseline.jpg"):
+        p = J.ParsedImage(fixture_bytes(name))
+        for i in range(2):
+            for k in range(2):
+                if p.image.ht[i][k]:
+                    h = B.zj_huff()  # a copy: the parsed image owns the original
+                    C.memmove(C.byref(h), p.image.ht[i][k], C.sizeof(h))
+                    tables.append(h)
+    rng = np.random.default_rng(11)
+    for _ in range(40):
+        # random complete-or-incomplete prefix code: spend a Kraft budget of 2^16 over lengths 1..16
+        counts, budget, nsym = [0] * 16, 1 << 16, 0
+        for l in range(1, 17):
+            unit = 1 << (16 - l)
+            room = min(budget // unit, 256 - nsym)
+            want = int(rng.integers(0, 3 + l)) if l < 14 else int(rng.integers(0, 120))
+            c = min(room, want)
+            counts[l - 1] = c
+            budget -= c * unit
+            nsym += c
+        if nsym == 0:
+            continue
+        h = B.zj_huff()
+        for i in range(16):
+            h.counts[i] = counts[i]
+        syms = rng.permutation(256)[:nsym]
+        for i, v in enumerate(syms):
+            h.symbols[i] = int(v)
+        tables.append(h)
+    assert len(tables) > 20
+    for h in tables:
+        for cap in (256, 64, 0):
+            assert S.zjsim_lookup_check(C.byref(h), cap, 20000, 5) == 0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Benchmark of the decode hot path: decoded megapixels/s on a batch of synthetic 1080p 4:2:0 q90
-baseline JPEGs (BASELINE.json configs[2]), device-resident timing, one process per GPU.
+baseline JPEGs (4096 images per GPU by default), device-resident timing, one process per GPU.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W

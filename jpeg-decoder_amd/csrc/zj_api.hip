@@ -153,7 +153,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
 
     b->imgs.resize(n);
     b->unsupported.assign(n, 0);
-    std::vector<uint32_t> chunk_seg, blk256_img, k1w_img, ptile_seg, tile_seg;
+    std::vector<uint32_t> chunk_seg, blk256_img, k1w_img, ptile_seg, tile_seg, dtile_seg;
     uint64_t nwin_total = 0;
     std::vector<uint32_t> k2_grp[4], k2_img[4]; // stage-2 workgroups per sampling layout
     std::vector<uint16_t> luts;
@@ -276,6 +276,9 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             const uint64_t mc = ri ? std::min<uint64_t>(ri, nmcu - m0) : nmcu;
             s.first_block = d.first_block + (uint32_t)(m0 * d.bpm);
             s.nblocks = (uint32_t)(mc * d.bpm);
+            s.first_dtile = (uint32_t)dtile_seg.size();
+            s.ndtiles = (uint32_t)std::max<uint64_t>(1, (mc + 255u) / 256u);
+            for (uint32_t t = 0; t < s.ndtiles; t++) dtile_seg.push_back((uint32_t)b->segs.size());
             b->segs.push_back(s);
         }
         d.nsub = (uint32_t)align_up(sub_in_img, 256);
@@ -311,6 +314,8 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.k1w_img = dev_upload(b, k1w_img);
     P.ptile_seg = dev_upload(b, ptile_seg);
     P.tile_seg = dev_upload(b, tile_seg);
+    P.dtile_seg = dev_upload(b, dtile_seg);
+    P.dtile_sum = dev_alloc<uint32_t>(b, dtile_seg.size() * 4, true);
     P.tile_status = dev_alloc<uint64_t>(b, tile_seg.size() + 1, true);
     P.tile_ticket = P.tile_status ? reinterpret_cast<uint32_t *>(P.tile_status + tile_seg.size()) : nullptr;
     std::vector<uint32_t> strip_grp_all, strip_img_all;
@@ -349,7 +354,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.rgb_stride = b->d_stride;
     P.nchunks = (uint32_t)chunk_seg.size();
     ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.wluts && P.canons && P.qts && raw && P.ust &&
-         P.seg_payload_bits && P.seg_found && P.winfo && P.wbase && P.bitmap && P.ptile_seg && P.tile_seg && P.tile_status && P.blockpos && P.dcabs && P.dcbits && P.qcoef && P.status &&
+         P.seg_payload_bits && P.seg_found && P.winfo && P.wbase && P.bitmap && P.ptile_seg && P.tile_seg && P.tile_status && P.dtile_seg && P.dtile_sum && P.blockpos && P.dcabs && P.dcbits && P.qcoef && P.status &&
          P.flags && b->d_rgb && b->d_stride;
     if (ok) ok = hip_ok(ctx, hipHostMalloc((void **)&b->h_rgb, (n ? n : 1) * sizeof(uint8_t *), hipHostMallocDefault), "hipHostMalloc") &&
                  hip_ok(ctx, hipHostMalloc((void **)&b->h_stride, (n ? n : 1) * sizeof(size_t), hipHostMallocDefault), "hipHostMalloc") &&
@@ -371,6 +376,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     b->L.nk1w = (uint32_t)k1w_img.size();
     b->L.nptiles = (uint32_t)ptile_seg.size();
     b->L.ntiles = (uint32_t)tile_seg.size();
+    b->L.ndtiles = (uint32_t)dtile_seg.size();
     b->L.nstrips = (uint32_t)strip_grp_all.size();
     b->L.fix_iters = 1;
     return b;

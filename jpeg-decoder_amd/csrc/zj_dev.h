@@ -30,6 +30,8 @@ struct ZjParams {
     uint32_t *wbase;            // per segment: [window in stream order] blocks that begin earlier in the segment
     uint8_t *bitmap;            // block-start bitmap, laid out like `ust` (one bit per stream bit)
     const uint32_t *ptile_seg;  // [position-pass workgroup] segment
+    const uint32_t *dtile_seg;  // [DC-scan tile of 256 MCUs] segment
+    uint32_t *dtile_sum;        // [DC-scan tile][4] per component: sum of the tile's differences, then of the tiles before it
     const uint32_t *tile_seg;   // [unstuff tile] segment
     uint64_t *tile_status;      // [unstuff tile] look-back word: flag << 32 | bytes; [ntiles] is the ticket counter
     uint32_t *tile_ticket;      // = (uint32_t *)&tile_status[ntiles]
@@ -55,7 +57,7 @@ struct ZjParams {
 #define ZJ_K2_NS 4 // strips per workgroup of the IDCT/colour kernel
 
 struct ZjLaunch {
-    uint32_t nseg, nchunks, nblk256, nstrips, nk1w, nptiles, ntiles;
+    uint32_t nseg, nchunks, nblk256, nstrips, nk1w, nptiles, ntiles, ndtiles;
     uint32_t k2_first[4], k2_count[4]; // stage-2 workgroups per sampling layout (2x2, 1x1, 2x1, 1x2)
     int fix_iters;
 };

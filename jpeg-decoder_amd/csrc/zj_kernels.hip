@@ -577,51 +577,98 @@ __global__ __launch_bounds__(256) void zj_k1c_dcdiff(ZjParams P)
 }
 
 // ---------------------------------------------------------------------------------- k1d: DC scan
-// One workgroup per segment, one lane per MCU per step.  dc[g] = sum of the DC differences of the
-// same component up to and including block g, i16 wrapping (src/decoder.rs:199-200; the predictors
-// start at 0 in every segment, :376).
-__global__ __launch_bounds__(256) void zj_k1d_dcscan(ZjParams P)
+// dc[g] = sum of the DC differences of the same component up to and including block g, i16 wrapping
+// (src/decoder.rs:199-200; the predictors start at 0 in every segment, :376).  A segment is cut into
+// tiles of 256 MCUs (one lane per MCU), so that one long segment -- an image without restart markers
+// -- is scanned by many workgroups: (1) per tile the sums of its differences per component, (2) per
+// segment the exclusive scan of the tile sums, (3) per tile the scan of its own blocks on top of that.
+struct ZjDcTile {
+    uint32_t d[6], loc[3]; // this lane's differences, and their sums per component
+};
+
+__device__ __forceinline__ ZjDcTile zj_dc_tile_load(const int16_t *da, uint32_t m, uint32_t nmcu, uint32_t bpm, uint32_t compsel)
+{
+    ZjDcTile t;
+#pragma unroll
+    for (uint32_t cc = 0; cc < 3u; cc++) t.loc[cc] = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 6u; k++) {
+        t.d[k] = 0;
+        if (k < bpm && m < nmcu) t.d[k] = (uint32_t)(int32_t)da[m * bpm + k];
+        const uint32_t c = (compsel >> (2u * k)) & 3u;
+#pragma unroll
+        for (uint32_t cc = 0; cc < 3u; cc++)
+            if (c == cc && k < bpm) t.loc[cc] += t.d[k];
+    }
+    return t;
+}
+
+__global__ __launch_bounds__(256) void zj_k1d_tilesum(ZjParams P)
+{
+    __shared__ uint32_t wsum[8];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t s = P.dtile_seg[tile];
+    const ZjSegDev sg = P.segs[s];
+    if (sg.ndtiles == 1u) return; // nothing before its only tile
+    const ZjImgDev &im = P.imgs[sg.img];
+    const uint32_t nmcu = sg.nblocks / im.bpm;
+    const uint32_t m = (tile - sg.first_dtile) * 256u + threadIdx.x;
+    const ZjDcTile t = zj_dc_tile_load(P.dcabs + sg.first_block, m, nmcu, im.bpm, im.compsel);
+    uint32_t tot[3];
+#pragma unroll
+    for (uint32_t cc = 0; cc < 3u; cc++) (void)block_incl_scan<4>(t.loc[cc], wsum, &tot[cc]);
+    if (threadIdx.x < 3u) P.dtile_sum[(size_t)tile * 4u + threadIdx.x] = tot[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void zj_k1d_tilescan(ZjParams P)
 {
     __shared__ uint32_t wsum[8];
     const uint32_t s = blockIdx.x;
     const ZjSegDev sg = P.segs[s];
-    const ZjImgDev &im = P.imgs[sg.img];
-    const uint32_t bpm = im.bpm, compsel = im.compsel;
-    const uint32_t found = min(P.seg_found[s], sg.nblocks);
-    const uint32_t nmcu = sg.nblocks / bpm;
-    int16_t *da = P.dcabs + sg.first_block; // holds the differences on entry
-    (void)found;
+    if (sg.ndtiles == 1u) return;
+    uint32_t *ts = P.dtile_sum + (size_t)sg.first_dtile * 4u;
     uint32_t carry[3] = {0, 0, 0};
-    for (uint32_t m0 = 0; m0 < nmcu; m0 += 256u) {
-        const uint32_t m = m0 + threadIdx.x;
-        uint32_t d[6] = {0, 0, 0, 0, 0, 0}, loc[3] = {0, 0, 0};
-#pragma unroll
-        for (uint32_t k = 0; k < 6u; k++) {
-            uint32_t g = m * bpm + k;
-            if (k < bpm && m < nmcu) d[k] = (uint32_t)(int32_t)da[g];
-            uint32_t c = (compsel >> (2u * k)) & 3u;
-#pragma unroll
-            for (uint32_t cc = 0; cc < 3u; cc++)
-                if (c == cc && k < bpm) loc[cc] += d[k];
-        }
-        uint32_t run[3];
+    for (uint32_t t0 = 0; t0 < sg.ndtiles; t0 += 256u) {
+        const uint32_t t = t0 + threadIdx.x;
 #pragma unroll
         for (uint32_t cc = 0; cc < 3u; cc++) {
+            const uint32_t v = t < sg.ndtiles ? ts[(size_t)t * 4u + cc] : 0u;
             uint32_t total;
-            uint32_t inc = block_incl_scan<4>(loc[cc], wsum, &total);
-            run[cc] = carry[cc] + inc - loc[cc];
+            const uint32_t inc = block_incl_scan<4>(v, wsum, &total);
+            if (t < sg.ndtiles) ts[(size_t)t * 4u + cc] = carry[cc] + inc - v; // in place: sum -> sum of the tiles before
             carry[cc] += total;
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void zj_k1d_dcscan(ZjParams P)
+{
+    __shared__ uint32_t wsum[8];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t s = P.dtile_seg[tile];
+    const ZjSegDev sg = P.segs[s];
+    const ZjImgDev &im = P.imgs[sg.img];
+    const uint32_t bpm = im.bpm, compsel = im.compsel;
+    const uint32_t nmcu = sg.nblocks / bpm;
+    int16_t *da = P.dcabs + sg.first_block; // holds the differences on entry
+    const uint32_t m = (tile - sg.first_dtile) * 256u + threadIdx.x;
+    const ZjDcTile t = zj_dc_tile_load(da, m, nmcu, bpm, compsel);
+    uint32_t run[3];
 #pragma unroll
-        for (uint32_t k = 0; k < 6u; k++) {
-            uint32_t g = m * bpm + k;
-            uint32_t c = (compsel >> (2u * k)) & 3u;
-            uint32_t v = 0;
+    for (uint32_t cc = 0; cc < 3u; cc++) {
+        const uint32_t before = sg.ndtiles == 1u ? 0u : P.dtile_sum[(size_t)tile * 4u + cc];
+        uint32_t total;
+        const uint32_t inc = block_incl_scan<4>(t.loc[cc], wsum, &total);
+        run[cc] = before + inc - t.loc[cc];
+    }
 #pragma unroll
-            for (uint32_t cc = 0; cc < 3u; cc++)
-                if (c == cc && k < bpm) { run[cc] += d[k]; v = run[cc]; }
-            if (k < bpm && m < nmcu) da[g] = (int16_t)v;
-        }
+    for (uint32_t k = 0; k < 6u; k++) {
+        const uint32_t c = (compsel >> (2u * k)) & 3u;
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t cc = 0; cc < 3u; cc++)
+            if (c == cc && k < bpm) { run[cc] += t.d[k]; v = run[cc]; }
+        if (k < bpm && m < nmcu) da[m * bpm + k] = (int16_t)v;
     }
 }
 
@@ -1132,7 +1179,11 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1c_dcdiff, dim3(L.nblk256), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.nseg), dim3(256), 0, st, P);
+    if (L.ndtiles) {
+        hipLaunchKernelGGL(zj_k1d_tilesum, dim3(L.ndtiles), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(zj_k1d_tilescan, dim3(L.nseg), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.ndtiles), dim3(256), 0, st, P);
+    }
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
@@ -1148,7 +1199,11 @@ extern "C" void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipS
     hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
     if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1c_dcdiff, dim3(L.nblk256), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.nseg), dim3(256), 0, st, P);
+    if (L.ndtiles) {
+        hipLaunchKernelGGL(zj_k1d_tilesum, dim3(L.ndtiles), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(zj_k1d_tilescan, dim3(L.nseg), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.ndtiles), dim3(256), 0, st, P);
+    }
     hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
 }
 

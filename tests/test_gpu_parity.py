@@ -194,6 +194,34 @@ def test_corrupt_streams_set_status_not_faults(ctx):
     assert ok_blocks > 0
 
 
+def test_fuzzed_streams_give_the_same_status_at_every_subsequence_size(ctx):
+    """Random damage to the entropy data (bit flips, random bytes, stray FF bytes, truncation) of images with
+    and without restart markers: no fault, no hang, no device error, and the status words do not depend on how
+    the stream was cut into subsequences."""
+    rng = np.random.default_rng(123)
+    files = []
+    for b in (synth.encode(256, 256, 2, 2, 90, 0, 1, 0), synth.encode(200, 120, 1, 1, 90, 2, 2, 8)):
+        info = oracle.probe(b)
+        for _ in range(30):
+            d = bytearray(b)
+            for k in rng.integers(info.scan_off, info.scan_off + info.scan_len - 2, int(rng.integers(1, 30))):
+                mode = rng.integers(0, 3)
+                d[k] = (d[k] ^ (1 << int(rng.integers(0, 8)))) if mode == 0 else (int(rng.integers(0, 256)) if mode == 1 else 0xFF)
+            if rng.integers(0, 4) == 0:
+                d = d[: int(rng.integers(info.scan_off + 4, info.scan_off + info.scan_len))] + b"\xff\xd9"
+            files.append(bytes(d))
+    imgs = []
+    for f in files:
+        try:
+            imgs.append(J.ParsedImage(f))
+        except J.DecodeError:
+            pass
+    assert len(imgs) > 40
+    sts = [J.decode_images(ctx, imgs, subseq_bits=sb)[1] for sb in (0, 512, 16384)]
+    assert np.array_equal(sts[0], sts[1]) and np.array_equal(sts[0], sts[2])
+    assert (sts[0] != 0).sum() > len(imgs) // 2
+
+
 def test_one_shot_entry_point_host_outputs(ctx):
     """zj_decode_batch with host output pointers (the call shape of the reference: file in, pixels out)."""
     data = fixture_bytes("porsche.jpg")

@@ -28,7 +28,7 @@ extern "C" {
 #define ZJ_OK 0
 #define ZJ_E_INVALID (-1)     /* bad argument                                                       */
 #define ZJ_E_FORMAT (-2)      /* malformed container (the reference panics: src/decoder.rs:358 ...) */
-#define ZJ_E_UNSUPPORTED (-3) /* valid JPEG outside the path (progressive, 16-bit DQT, 1 component) */
+#define ZJ_E_UNSUPPORTED (-3) /* valid JPEG outside the path (progressive, 12-bit, 4 components)     */
 #define ZJ_E_DEVICE (-4)      /* HIP runtime error or no usable GPU; see zj_last_error              */
 #define ZJ_E_NOMEM (-5)
 #define ZJ_E_IO (-6)          /* counterpart of DecodeError::Io (src/error.rs:4-6)                  */
@@ -59,7 +59,7 @@ typedef struct zj_image {
     const uint8_t *scan;
     size_t scan_len;
     uint16_t width, height;
-    uint8_t ncomp;       /* 3 */
+    uint8_t ncomp;       /* 3, or 1 (grayscale: entries [0] only; hsamp[0] = vsamp[0] = 1) */
     uint8_t hsamp[3];    /* luma 1 or 2, chroma 1 */
     uint8_t vsamp[3];
     uint8_t tq[3];       /* component -> quantisation table id */

@@ -155,7 +155,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     b->unsupported.assign(n, 0);
     std::vector<uint32_t> chunk_seg, blk256_img, k1w_img, ptile_seg, tile_seg, dtile_seg;
     uint64_t nwin_total = 0;
-    std::vector<uint32_t> k2_grp[4], k2_img[4]; // stage-2 workgroups per sampling layout
+    std::vector<uint32_t> k2_grp[ZJ_K2_CLASSES], k2_img[ZJ_K2_CLASSES]; // stage-2 workgroups per sampling layout
     std::vector<uint16_t> luts;
     std::vector<ZjCanon> canons;
     std::vector<uint16_t> qts;
@@ -177,7 +177,8 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
         d.flags = 1;
         d.w = im.width; d.h = im.height;
         d.hs = im.hsamp[0]; d.vs = im.vsamp[0];
-        d.bpm = d.hs * d.vs + 2;
+        const uint32_t ncomp = im.ncomp;
+        d.bpm = ncomp == 1 ? 1u : d.hs * d.vs + 2;
         d.mcux = (d.w + 8 * d.hs - 1) / (8 * d.hs);
         d.mcuy = (d.h + 8 * d.vs - 1) / (8 * d.vs);
         const uint64_t nmcu = (uint64_t)d.mcux * d.mcuy;
@@ -218,7 +219,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             }
         }
         for (int c = 0; c < 3; c++) {
-            std::string key((const char *)im.qt[im.tq[c]], 64);
+            std::string key((const char *)im.qt[im.tq[c < (int)ncomp ? c : 0]], 64);
             auto it = qt_ids.find(key);
             if (it == qt_ids.end()) {
                 it = qt_ids.emplace(key, (uint32_t)qts.size()).first;
@@ -295,7 +296,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
         const uint32_t T = 96 / d.bpm;
         d.strips_x = (d.mcux + T - 1) / T;
         const uint32_t ns = (d.strips_x * d.mcuy + ZJ_K2_NS - 1) / ZJ_K2_NS; // workgroups of stage 2
-        const int cls = (d.hs == 2 && d.vs == 2) ? 0 : (d.hs == 1 && d.vs == 1) ? 1 : (d.hs == 2) ? 2 : 3;
+        const int cls = ncomp == 1 ? 4 : (d.hs == 2 && d.vs == 2) ? 0 : (d.hs == 1 && d.vs == 1) ? 1 : (d.hs == 2) ? 2 : 3;
         for (uint32_t s = 0; s < ns; s++) { k2_grp[cls].push_back(s); k2_img[cls].push_back((uint32_t)i); }
         nstrip_total += ns;
         b->scan_bytes += im.scan_len;
@@ -319,7 +320,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.tile_status = dev_alloc<uint64_t>(b, tile_seg.size() + 1, true);
     P.tile_ticket = P.tile_status ? reinterpret_cast<uint32_t *>(P.tile_status + tile_seg.size()) : nullptr;
     std::vector<uint32_t> strip_grp_all, strip_img_all;
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < ZJ_K2_CLASSES; c++) {
         b->L.k2_first[c] = (uint32_t)strip_grp_all.size();
         b->L.k2_count[c] = (uint32_t)k2_grp[c].size();
         strip_grp_all.insert(strip_grp_all.end(), k2_grp[c].begin(), k2_grp[c].end());
@@ -411,7 +412,7 @@ extern "C" int zj_batch_decode(zj_batch *b, uint8_t *const *rgb, const size_t *s
     }
     zj_launch_stage1(b->P, b->L, st, ev);
     ZjLaunch L2 = b->L;
-    if (!any_rgb) { L2.nstrips = 0; for (int c = 0; c < 4; c++) L2.k2_count[c] = 0; }
+    if (!any_rgb) { L2.nstrips = 0; for (int c = 0; c < ZJ_K2_CLASSES; c++) L2.k2_count[c] = 0; }
     zj_launch_stage2(b->P, L2, st, ev ? ev + 8 : nullptr);
     if (!hip_ok(c, hipGetLastError(), "kernel launch")) return ZJ_E_DEVICE;
     b->decoded = true;
@@ -442,7 +443,7 @@ extern "C" int zj_batch_finish(zj_batch *b, uint32_t *status)
             bool any_rgb = false;
             for (size_t i = 0; i < b->n; i++) any_rgb = any_rgb || b->h_rgb[i];
             ZjLaunch L2 = b->L;
-            if (!any_rgb) { L2.nstrips = 0; for (int c = 0; c < 4; c++) L2.k2_count[c] = 0; }
+            if (!any_rgb) { L2.nstrips = 0; for (int c = 0; c < ZJ_K2_CLASSES; c++) L2.k2_count[c] = 0; }
             zj_launch_stage2(b->P, L2, st, nullptr);
             if (!hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
             if (!hip_ok(c, hipMemcpy(b->h_flags, b->P.flags, 16, hipMemcpyDeviceToHost), "D2H flags")) return ZJ_E_DEVICE;

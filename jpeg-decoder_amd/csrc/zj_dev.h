@@ -55,10 +55,11 @@ struct ZjParams {
 };
 
 #define ZJ_K2_NS 4 // strips per workgroup of the IDCT/colour kernel
+#define ZJ_K2_CLASSES 5
 
 struct ZjLaunch {
     uint32_t nseg, nchunks, nblk256, nstrips, nk1w, nptiles, ntiles, ndtiles;
-    uint32_t k2_first[4], k2_count[4]; // stage-2 workgroups per sampling layout (2x2, 1x1, 2x1, 1x2)
+    uint32_t k2_first[ZJ_K2_CLASSES], k2_count[ZJ_K2_CLASSES]; // stage-2 workgroups per layout (2x2, 1x1, 2x1, 1x2, one component)
     int fix_iters;
 };
 

@@ -78,23 +78,30 @@ extern "C" int zj_parse(const uint8_t *file, size_t len, zj_parsed *out)
             }
             break;
         case 0xc0: { // SOF0 (src/decoder.rs:564-630)
-            if (seglen < 8 + 3 * 3) return ZJ_E_FORMAT;
+            if (seglen < 8 + 3) return ZJ_E_FORMAT;
             const int prec = r.u8();
             const int h = r.u16(), w = r.u16();
             const int nc = r.u8();
             if (prec != 8) return ZJ_E_UNSUPPORTED;
-            if (nc != 3) return ZJ_E_UNSUPPORTED; // the MCU loop is three-component, :170-173
+            // three components, or one (admitted at :574-575; the reference's MCU loop, :170-173, cannot
+            // decode it: here a one-component frame is single blocks in raster order, T.81 A.2.2)
+            if (nc != 3 && nc != 1) return ZJ_E_UNSUPPORTED;
+            if (seglen < 8 + 3 * (size_t)nc) return ZJ_E_FORMAT;
             if (w <= 0 || h <= 0) return ZJ_E_FORMAT;
             im.width = (uint16_t)w;
             im.height = (uint16_t)h;
-            im.ncomp = 3;
-            for (int c = 0; c < 3; c++) {
+            im.ncomp = (uint8_t)nc;
+            for (int c = 0; c < nc; c++) {
                 (void)r.u8();
                 const int s = r.u8();
                 im.hsamp[c] = (uint8_t)(s >> 4);
                 im.vsamp[c] = (uint8_t)(s & 0xf);
                 im.tq[c] = (uint8_t)r.u8();
                 if (im.tq[c] > 3) return ZJ_E_FORMAT;
+            }
+            if (nc == 1) { // never interleaved: the sampling factors of a lone component do not matter
+                im.hsamp[0] = im.vsamp[0] = 1;
+                for (int c = 1; c < 3; c++) { im.hsamp[c] = im.vsamp[c] = 1; im.tq[c] = im.tq[0]; }
             }
             seen_sof = true;
             break;
@@ -105,14 +112,15 @@ extern "C" int zj_parse(const uint8_t *file, size_t len, zj_parsed *out)
         case 0xda: { // SOS (src/decoder.rs:366-370; the selectors the reference skips are read here)
             if (!seen_sof) return ZJ_E_FORMAT;
             const int ns = r.u8();
-            if (ns != 3) return ZJ_E_UNSUPPORTED; // one interleaved scan
-            for (int c = 0; c < 3; c++) {
+            if (ns != im.ncomp) return ZJ_E_UNSUPPORTED; // one scan with all components
+            for (int c = 0; c < ns; c++) {
                 (void)r.u8();
                 const int t = r.u8();
                 im.td[c] = (uint8_t)(t >> 4);
                 im.ta[c] = (uint8_t)(t & 0xf);
                 if (im.td[c] > 1 || im.ta[c] > 1) return ZJ_E_UNSUPPORTED;
             }
+            for (int c = ns; c < 3; c++) { im.td[c] = im.td[0]; im.ta[c] = im.ta[0]; }
             r.pos = seg_end;
             // extent of the entropy-coded data: up to the first marker other than FF00 / RSTn
             size_t p = r.pos;
@@ -134,7 +142,7 @@ extern "C" int zj_parse(const uint8_t *file, size_t len, zj_parsed *out)
             for (int t = 0; t < 4; t++) im.qt[t] = qt_def[t] ? out->qt_store[t] : nullptr;
             for (int id = 0; id < 2; id++)
                 for (int k = 0; k < 2; k++) im.ht[id][k] = ht_def[id][k] ? &out->ht_store[id][k] : nullptr;
-            for (int c = 0; c < 3; c++) {
+            for (int c = 0; c < im.ncomp; c++) {
                 if (!im.qt[im.tq[c]] || !im.ht[im.td[c]][1] || !im.ht[im.ta[c]][0]) return ZJ_E_FORMAT;
             }
             return zj_image_supported(&im) ? ZJ_OK : ZJ_E_UNSUPPORTED;
@@ -149,10 +157,11 @@ extern "C" int zj_parse(const uint8_t *file, size_t len, zj_parsed *out)
 
 bool zj_image_supported(const zj_image *im)
 {
-    if (!im || im->ncomp != 3 || !im->width || !im->height || !im->scan) return false;
+    if (!im || (im->ncomp != 3 && im->ncomp != 1) || !im->width || !im->height || !im->scan) return false;
+    if (im->ncomp == 1 && (im->hsamp[0] != 1 || im->vsamp[0] != 1)) return false;
     if (im->hsamp[0] < 1 || im->hsamp[0] > 2 || im->vsamp[0] < 1 || im->vsamp[0] > 2) return false;
-    if (im->hsamp[1] != 1 || im->vsamp[1] != 1 || im->hsamp[2] != 1 || im->vsamp[2] != 1) return false;
-    for (int c = 0; c < 3; c++) {
+    if (im->ncomp == 3 && (im->hsamp[1] != 1 || im->vsamp[1] != 1 || im->hsamp[2] != 1 || im->vsamp[2] != 1)) return false;
+    for (int c = 0; c < im->ncomp; c++) {
         if (im->tq[c] > 3 || im->td[c] > 1 || im->ta[c] > 1) return false;
         if (!im->qt[im->tq[c]] || !im->ht[im->td[c]][1] || !im->ht[im->ta[c]][0]) return false;
     }
@@ -168,7 +177,7 @@ extern "C" uint32_t zj_image_mcus(const zj_image *im)
 
 extern "C" uint32_t zj_image_blocks(const zj_image *im)
 {
-    return zj_image_mcus(im) * (uint32_t)(im->hsamp[0] * im->vsamp[0] + 2);
+    return zj_image_mcus(im) * (im->ncomp == 1 ? 1u : (uint32_t)(im->hsamp[0] * im->vsamp[0] + 2));
 }
 
 extern "C" size_t zj_restart_offsets(const zj_image *im, size_t *offsets, size_t cap)

@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
     const uint32_t m0 = ((blockIdx.x - im.first_k1w) * 4u + wave) * M; // first MCU of this wavefront
     const uint32_t nmcu = im.nblocks / bpm;
     if (m0 >= nmcu) return; // wave-uniform
-    const uint32_t rounds_l = (M << shl) / 64u, rounds = rounds_l + M * 2u / 64u;
+    const uint32_t rounds_l = (M << shl) / 64u, rounds = rounds_l + M * (bpm - nl) / 64u; // no chroma rounds for one component
     uint32_t *row32 = &tile[wave][lane * 33u];
     int16_t *row = reinterpret_cast<int16_t *>(row32);
     uint32_t *col = &scol[wave][lane];
@@ -1145,6 +1145,123 @@ __global__ __launch_bounds__(256) void zj_k2_idct_rgb(ZjParams P, uint32_t first
     zj_k2_body<HS, VS>(P, im, ii, s0, s1, blk, qlds);
 }
 
+// One-component frames: every MCU is a single block and the pixels are those of a colour image
+// with Cb = Cr = 128, where src/decoder.rs:271-273 gives r = 1.402f * 0 + y = y and likewise g and b:
+// the three bytes of a pixel are the same truncated, saturated luma value.
+__global__ __launch_bounds__(256) void zj_k2_idct_gray(ZjParams P, uint32_t first)
+{
+    constexpr int T = ZJ_K2_BLOCKS, TW = T / 4;   // blocks (= MCUs) per strip and per wavefront
+    constexpr int ROWB = TW * 24, ROWP = ROWB + 16, PIECES = ROWB / 16;
+    __shared__ __attribute__((aligned(16))) float blk_all[ZJ_K2_BLOCKS * ZJ_K2_BSTRIDE];
+    __shared__ __attribute__((aligned(16))) uint16_t qlds[64];
+    const uint32_t grp = P.strip_img[first + blockIdx.x];
+    const uint32_t ii = P.strip_img_img[first + blockIdx.x];
+    const ZjImgDev &im = P.imgs[ii];
+    if (threadIdx.x < 64u) qlds[threadIdx.x] = P.qts[im.qt_off[0] + threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float *blk = blk_all + wave * (ZJ_K2_WBLOCKS * ZJ_K2_BSTRIDE);
+    uint8_t *rgb = P.rgb[ii];
+    if (rgb == nullptr) return;
+    const size_t stride = P.rgb_stride[ii] ? P.rgb_stride[ii] : (size_t)im.w * 3u;
+    const bool vec_ok = (((uintptr_t)rgb | stride) & 15u) == 0;
+    const uint32_t part = lane & 7u;
+    uint32_t off[8];
+    {
+        const uint64_t natb = zj_zz2nat_bytes[part];
+#pragma unroll
+        for (int e = 0; e < 8; e++) off[e] = (uint32_t)(natb >> (8 * e)) & 0xFFu;
+    }
+    const uint4 qv = reinterpret_cast<const uint4 *>(qlds)[part];
+    const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
+    const uint32_t nstrips = im.strips_x * im.mcuy;
+    const uint32_t s0 = grp * ZJ_K2_NS, s1 = min(s0 + ZJ_K2_NS, nstrips);
+    for (uint32_t strip = s0; strip < s1; strip++) {
+        const uint32_t my = strip / im.strips_x, sx = strip % im.strips_x;
+        const uint32_t x0 = sx * T + wave * TW; // first block of this wavefront in the block row
+        const uint32_t nbw = x0 < im.mcux ? min((uint32_t)TW, im.mcux - x0) : 0u;
+        const int16_t *src = P.qcoef + ((size_t)im.first_block + (size_t)my * im.mcux + x0) * 64u;
+        // dequantise and de-zigzag into LDS (src/decoder.rs:179-184, :296-300)
+#pragma unroll
+        for (uint32_t i = 0; i < 3u; i++) {
+            const uint32_t q = lane + i * 64u, b = q >> 3;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (b < nbw) v = *reinterpret_cast<const uint4 *>(src + (size_t)q * 8u);
+            const uint32_t cw[4] = {v.x, v.y, v.z, v.w};
+            char *bp = reinterpret_cast<char *>(blk + b * ZJ_K2_BSTRIDE);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const zj_u16x2 pr = __builtin_bit_cast(zj_u16x2, cw[j]) * __builtin_bit_cast(zj_u16x2, qw[j]);
+                *reinterpret_cast<float *>(bp + off[2 * j]) = (float)(int16_t)pr.x;
+                *reinterpret_cast<float *>(bp + off[2 * j + 1]) = (float)(int16_t)pr.y;
+            }
+        }
+        zj_wave_lds_sync();
+        // columns in place (src/dct.rs:104-111)
+#pragma unroll
+        for (uint32_t i = 0; i < 3u; i++) {
+            const uint32_t q = lane + i * 64u;
+            float *bp = blk + (q >> 3) * ZJ_K2_BSTRIDE + (q & 7u);
+            float in[8], out[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) in[k] = bp[k * 8];
+            zj_idct_1d(in, out);
+#pragma unroll
+            for (int n = 0; n < 8; n++) bp[n * 8] = out[n];
+        }
+        zj_wave_lds_sync();
+        // rows (src/dct.rs:113-120), +128, three equal bytes per pixel: one lane per (block, row)
+        uint32_t px[3][6];
+#pragma unroll
+        for (uint32_t i = 0; i < 3u; i++) {
+            const uint32_t q = lane + i * 64u;
+            const float *bp = blk + (q >> 3) * ZJ_K2_BSTRIDE + (q & 7u) * 8u;
+            float in[8], y[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) in[k] = bp[k];
+            zj_idct_1d(in, y);
+#pragma unroll
+            for (int w4 = 0; w4 < 6; w4++) px[i][w4] = 0;
+#pragma unroll
+            for (int x = 0; x < 8; x++) {
+                // src/decoder.rs:271-273 with cb = cr = 128: the products are +-0 and every sum is the luma value
+                const float yv = y[x] + 128.0f;
+                const float r = yv, g = yv, b2 = yv;
+                px[i][(3 * x + 0) >> 2] = zj_pack_u8(r, (3 * x + 0) & 3, px[i][(3 * x + 0) >> 2]);
+                px[i][(3 * x + 1) >> 2] = zj_pack_u8(g, (3 * x + 1) & 3, px[i][(3 * x + 1) >> 2]);
+                px[i][(3 * x + 2) >> 2] = zj_pack_u8(b2, (3 * x + 2) & 3, px[i][(3 * x + 2) >> 2]);
+            }
+        }
+        zj_wave_lds_sync();
+        char *stage = reinterpret_cast<char *>(blk);
+#pragma unroll
+        for (uint32_t i = 0; i < 3u; i++) {
+            const uint32_t q = lane + i * 64u;
+            char *d = stage + (q & 7u) * ROWP + (q >> 3) * 24u;
+#pragma unroll
+            for (int w4 = 0; w4 < 6; w4 += 2) *reinterpret_cast<uint2 *>(d + 4 * w4) = make_uint2(px[i][w4], px[i][w4 + 1]);
+        }
+        zj_wave_lds_sync();
+        const uint32_t xb = x0 * 24u;
+        const uint32_t row_valid = min((uint32_t)ROWB, (im.w - min(im.w, x0 * 8u)) * 3u);
+        const uint32_t rows_valid = min(8u, im.h - min(im.h, my * 8u));
+        for (uint32_t q = lane; q < (uint32_t)(PIECES * 8); q += 64u) {
+            const uint32_t r = q / PIECES, o = (q % PIECES) * 16u;
+            if (r >= rows_valid || o >= row_valid) continue;
+            uint8_t *dst = rgb + (size_t)(my * 8u + r) * stride + xb + o;
+            const uint4 pv = *reinterpret_cast<const uint4 *>(stage + r * ROWP + o);
+            if (vec_ok && o + 16u <= row_valid) {
+                *reinterpret_cast<uint4 *>(dst) = pv;
+            } else {
+                const uint32_t s4[4] = {pv.x, pv.y, pv.z, pv.w};
+                const uint32_t nbytes = min(16u, row_valid - o);
+                for (uint32_t k = 0; k < nbytes; k++) dst[k] = (uint8_t)(s4[k >> 2] >> (8u * (k & 3u)));
+            }
+        }
+        zj_wave_lds_sync();
+    }
+}
+
 // ---------------------------------------------------------------------------------- export (tests)
 // dqcoef[b][nat] = qcoef[b][zz] * q[zz]: the reference's `blocks` entry (src/decoder.rs:237-240).
 __global__ __launch_bounds__(256) void zj_kx_dequant(ZjParams P, uint32_t ii, int16_t *dst)
@@ -1214,6 +1331,7 @@ extern "C" void zj_launch_stage2(const ZjParams &P, const ZjLaunch &L, hipStream
     if (L.k2_count[1]) hipLaunchKernelGGL((zj_k2_idct_rgb<1, 1>), dim3(L.k2_count[1]), dim3(256), 0, st, P, L.k2_first[1]);
     if (L.k2_count[2]) hipLaunchKernelGGL((zj_k2_idct_rgb<2, 1>), dim3(L.k2_count[2]), dim3(256), 0, st, P, L.k2_first[2]);
     if (L.k2_count[3]) hipLaunchKernelGGL((zj_k2_idct_rgb<1, 2>), dim3(L.k2_count[3]), dim3(256), 0, st, P, L.k2_first[3]);
+    if (L.k2_count[4]) hipLaunchKernelGGL(zj_k2_idct_gray, dim3(L.k2_count[4]), dim3(256), 0, st, P, L.k2_first[4]);
     if (ev) hipEventRecord(ev[0], st);
 }
 

@@ -24,7 +24,8 @@ def lib():
 
 
 def encode(w, h, hs=2, vs=2, quality=90, content=NATURAL, seed=0, restart_interval=0) -> bytes:
-    """One synthetic image as JPEG file bytes.  (hs, vs) = luma sampling: (2,2) is 4:2:0, (1,1) is 4:4:4."""
+    """One synthetic image as JPEG file bytes.  (hs, vs) = luma sampling: (2,2) is 4:2:0, (1,1) is 4:4:4,
+    (0,0) is a one-component (grayscale) file that codes the luma plane of the same content."""
     n = C.c_size_t()
     p = lib().zj_synth_encode(w, h, hs, vs, quality, content, seed, restart_interval, C.byref(n))
     if not p:

@@ -2,7 +2,7 @@
  * zj_synth.c -- deterministic synthetic baseline-JPEG generator (workload generator for the
  * benchmark and the tests; CPU only, no part of the decode path).
  *
- * Produces baseline sequential (SOF0) 8-bit, 3-component, single interleaved scan files with
+ * Produces baseline sequential (SOF0) 8-bit, 3-component (or, on request, 1-component), single-scan files with
  * the T.81 Annex K example quantisation tables scaled by the IJG quality formula and the Annex K
  * typical Huffman tables, optional restart intervals (DRI + RST0..7 cycling).
  *
@@ -228,12 +228,15 @@ static void fetch_block(const float *plane, int pw, int ph, int bx, int by, int 
 
 /*
  * Encode one synthetic image.  hs, vs: luma sampling factors (1 or 2); chroma is 1x1.
+ * hs = vs = 0: a one-component (grayscale) file that codes the luma plane of the same content.
  * content class: 0 natural, 1 smooth, 2 white noise.  restart_interval in MCUs (0 = none).
  * Returns a malloc'd buffer (free with zj_synth_free) and its size in *out_len.
  */
 uint8_t *zj_synth_encode(int w, int h, int hs, int vs, int quality, int content_class, uint64_t seed,
                          int restart_interval, size_t *out_len)
 {
+    const int gray = (hs == 0 && vs == 0);
+    if (gray) hs = vs = 1;
     if (w < 1 || h < 1 || w > 65535 || h > 65535 || hs < 1 || hs > 2 || vs < 1 || vs > 2) return NULL;
     float *Y = (float *)malloc(sizeof(float) * (size_t)w * h);
     float *Cb = (float *)malloc(sizeof(float) * (size_t)w * h);
@@ -259,10 +262,15 @@ uint8_t *zj_synth_encode(int w, int h, int hs, int vs, int quality, int content_
     put16(&o, 0xffdb); put16(&o, 2 + 65 * 2); /* one DQT segment, two tables, zig-zag order */
     put(&o, 0); for (int i = 0; i < 64; i++) put(&o, ql[k_zz2nat[i]]);
     put(&o, 1); for (int i = 0; i < 64; i++) put(&o, qc[k_zz2nat[i]]);
-    put16(&o, 0xffc0); put16(&o, 17); put(&o, 8); put16(&o, h); put16(&o, w); put(&o, 3);
-    put(&o, 1); put(&o, (hs << 4) | vs); put(&o, 0);
-    put(&o, 2); put(&o, 0x11); put(&o, 1);
-    put(&o, 3); put(&o, 0x11); put(&o, 1);
+    if (gray) {
+        put16(&o, 0xffc0); put16(&o, 11); put(&o, 8); put16(&o, h); put16(&o, w); put(&o, 1);
+        put(&o, 1); put(&o, 0x11); put(&o, 0);
+    } else {
+        put16(&o, 0xffc0); put16(&o, 17); put(&o, 8); put16(&o, h); put16(&o, w); put(&o, 3);
+        put(&o, 1); put(&o, (hs << 4) | vs); put(&o, 0);
+        put(&o, 2); put(&o, 0x11); put(&o, 1);
+        put(&o, 3); put(&o, 0x11); put(&o, 1);
+    }
     const uint8_t *hb[4] = {k_dc_lum_bits, k_ac_lum_bits, k_dc_chr_bits, k_ac_chr_bits};
     const uint8_t *hv[4] = {k_dc_vals, k_ac_lum_vals, k_dc_vals, k_ac_chr_vals};
     const int hinfo[4] = {0x00, 0x10, 0x01, 0x11};
@@ -274,8 +282,13 @@ uint8_t *zj_synth_encode(int w, int h, int hs, int vs, int quality, int content_
         for (int i = 0; i < n; i++) put(&o, hv[t][i]);
     }
     if (restart_interval > 0) { put16(&o, 0xffdd); put16(&o, 4); put16(&o, restart_interval); }
-    put16(&o, 0xffda); put16(&o, 12); put(&o, 3);
-    put(&o, 1); put(&o, 0x00); put(&o, 2); put(&o, 0x11); put(&o, 3); put(&o, 0x11);
+    if (gray) {
+        put16(&o, 0xffda); put16(&o, 8); put(&o, 1);
+        put(&o, 1); put(&o, 0x00);
+    } else {
+        put16(&o, 0xffda); put16(&o, 12); put(&o, 3);
+        put(&o, 1); put(&o, 0x00); put(&o, 2); put(&o, 0x11); put(&o, 3); put(&o, 0x11);
+    }
     put(&o, 0); put(&o, 63); put(&o, 0);
 
     int mcux = (w + 8 * hs - 1) / (8 * hs), mcuy = (h + 8 * vs - 1) / (8 * vs);
@@ -299,12 +312,14 @@ uint8_t *zj_synth_encode(int w, int h, int hs, int vs, int quality, int content_
                     fdct_quant(blk, ql, qz);
                     encode_block(&o, qz, &pred[0], &dcl, &acl);
                 }
-            fetch_block(Cb, w, h, mx, my, hs, vs, blk);
-            fdct_quant(blk, qc, qz);
-            encode_block(&o, qz, &pred[1], &dcc, &acc);
-            fetch_block(Cr, w, h, mx, my, hs, vs, blk);
-            fdct_quant(blk, qc, qz);
-            encode_block(&o, qz, &pred[2], &dcc, &acc);
+            if (!gray) {
+                fetch_block(Cb, w, h, mx, my, hs, vs, blk);
+                fdct_quant(blk, qc, qz);
+                encode_block(&o, qz, &pred[1], &dcc, &acc);
+                fetch_block(Cr, w, h, mx, my, hs, vs, blk);
+                fdct_quant(blk, qc, qz);
+                encode_block(&o, qz, &pred[2], &dcc, &acc);
+            }
             mcu_count++;
         }
     (void)total;

@@ -32,6 +32,8 @@
  *       Y->0, C->1 (src/decoder.rs:171-173, :368-370).  Identical on the reference's images.
  *   E5  widths/heights that are not multiples of the MCU size: ceil() blocks are decoded and the
  *       result cropped (the reference floors and skews rows, src/decoder.rs:284-285,314).
+ *   E6  one-component (grayscale) frames, which the reference admits at src/decoder.rs:574 but cannot
+ *       decode (:170-173): single blocks in raster order, pixels as for Cb = Cr = 128 (R = G = B).
  */
 #include <math.h>
 #include <stdint.h>
@@ -376,7 +378,10 @@ static int parse_headers(const uint8_t *file, size_t len, frame_t *f)
             int h = rd_u16(&r), w = rd_u16(&r);
             int nc = rd_u8(&r);
             if (prec != 8) return ZJO_E_UNSUPPORTED;
-            if (nc != 3) return ZJO_E_UNSUPPORTED; /* the decode loop is 3-component only, :170-173 */
+            /* The reference admits 1 or 3 components (:574) but its decode loop is 3-component only
+             * (:170-173).  Defined extension E6: a one-component frame is a sequence of single blocks in
+             * raster order (T.81 A.2.2), and its pixels are those of a colour image with Cb = Cr = 128. */
+            if (nc != 3 && nc != 1) return ZJO_E_UNSUPPORTED;
             if (w <= 0 || h <= 0) return ZJO_E_FORMAT;
             f->w = w; f->h = h; f->ncomp = nc;
             for (int c = 0; c < nc; c++) {
@@ -388,7 +393,10 @@ static int parse_headers(const uint8_t *file, size_t len, frame_t *f)
                 if (f->hs[c] > f->hmax) f->hmax = f->hs[c];
                 if (f->vs[c] > f->vmax) f->vmax = f->vs[c];
             }
-            if (f->hs[1] != 1 || f->vs[1] != 1 || f->hs[2] != 1 || f->vs[2] != 1) return ZJO_E_UNSUPPORTED;
+            if (nc == 1) { /* a single component is never interleaved: its sampling factors do not matter */
+                f->hs[0] = f->vs[0] = 1;
+                f->hmax = f->vmax = 1;
+            } else if (f->hs[1] != 1 || f->vs[1] != 1 || f->hs[2] != 1 || f->vs[2] != 1) return ZJO_E_UNSUPPORTED;
             seen_sof = 1;
         } else if (m >= 0xc1 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
             return ZJO_E_UNSUPPORTED; /* any other SOFn */
@@ -505,8 +513,11 @@ static void to_rgb(const frame_t *f, int mcux, int mcuy, int bpm, const int16_t 
                     int yb = (y2 / 8) * f->hs[0] + (x2 / 8);
                     float yp = out[yb][(y2 % 8) * 8 + (x2 % 8)] + 128.0f;
                     int cy = y2 / f->vmax, cx = x2 / f->hmax; /* chroma is 1x1: replicate */
-                    float cb = out[ny][cy * 8 + cx] + 128.0f;
-                    float cr = out[ny + 1][cy * 8 + cx] + 128.0f;
+                    float cb = 128.0f, cr = 128.0f;           /* E6: no chroma */
+                    if (f->ncomp == 3) {
+                        cb = out[ny][cy * 8 + cx] + 128.0f;
+                        cr = out[ny + 1][cy * 8 + cx] + 128.0f;
+                    }
                     ycbcr_to_rgb(yp, cb, cr, rgb + 3 * ((size_t)py * f->w + px));
                 }
             }

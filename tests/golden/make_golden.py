@@ -31,6 +31,8 @@ SYNTH_CASES = [
     ("s420_noise_256x256", 256, 256, 2, 2, 95, 2, 6, 0),
     ("s420_smooth_512x384", 512, 384, 2, 2, 50, 1, 7, 0),
     ("s444_rst1_64x64", 64, 64, 1, 1, 90, 0, 8, 1),
+    ("gray_300x200", 300, 200, 0, 0, 90, 0, 11, 0),        # hs = vs = 0: one component
+    ("gray_rst2_65x33", 65, 33, 0, 0, 75, 2, 12, 2),
 ]
 
 

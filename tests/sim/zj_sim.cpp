@@ -22,7 +22,7 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
 {
     if (!zj_image_supported(im)) return ZJ_E_UNSUPPORTED;
     memset(stats, 0, sizeof *stats);
-    const uint32_t hs = im->hsamp[0], vs = im->vsamp[0], bpm = hs * vs + 2;
+    const uint32_t hs = im->hsamp[0], vs = im->vsamp[0], bpm = im->ncomp == 1 ? 1u : hs * vs + 2;
     const uint32_t nmcu = zj_image_mcus(im);
     std::vector<uint16_t> lut(ZJ_SET_ENTRIES);
     ZjCanon canon[4];

@@ -52,6 +52,21 @@ def test_fixture_parity(ctx, name, subbits):
     b.close()
 
 
+def test_one_component_images(ctx):
+    """Grayscale files (one block per MCU, R = G = B): alone at several sizes, with restart markers, and in one
+    batch with colour images."""
+    files = [synth.encode(w, h, 0, 0, q, cls, seed, ri) for (w, h, q, cls, seed, ri) in
+             [(100, 60, 90, 0, 5, 0), (1, 1, 90, 0, 6, 0), (769, 9, 75, 2, 7, 0), (640, 480, 90, 0, 8, 5), (1920, 1080, 90, 0, 9, 0)]]
+    for data in files:
+        for sb in (0, 2048):
+            rgb, st, coef = J.decode_images(ctx, [J.ParsedImage(data)], subseq_bits=sb, want_coef=True)
+            assert_same(data, rgb[0], st[0], coef[0])
+    mixed = [files[0], synth.encode(200, 120, 2, 2, seed=2), files[3], synth.encode(90, 150, 1, 1, seed=4), files[2]]
+    rgb, st, coef = J.decode_images(ctx, [J.ParsedImage(f) for f in mixed], want_coef=True)
+    for f, r, s_, c in zip(mixed, rgb, st, coef):
+        assert_same(f, r, s_, c)
+
+
 def test_canonical_search_path(ctx):
     """Tables built without their second level: every code longer than nine bits is found by the canonical
     search inside the kernels (the path that only unusual tables reach otherwise)."""

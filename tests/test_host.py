@@ -106,6 +106,7 @@ def test_stage1_walk_fixtures(name, subbits):
     (320, 240, 2, 2, 90, 0, 1, 0), (200, 120, 1, 1, 90, 0, 2, 0), (150, 90, 2, 1, 75, 0, 3, 0),
     (90, 150, 1, 2, 75, 0, 4, 0), (333, 211, 2, 2, 90, 0, 5, 4), (256, 256, 2, 2, 95, 2, 6, 0),
     (512, 384, 2, 2, 50, 1, 7, 0), (64, 64, 1, 1, 90, 0, 8, 1), (8, 8, 1, 1, 90, 0, 9, 0), (17, 9, 2, 2, 90, 0, 10, 1),
+    (300, 200, 0, 0, 90, 0, 11, 0), (65, 33, 0, 0, 75, 2, 12, 2),
 ])
 def test_stage1_walk_synthetic(params):
     data = synth.encode(*params)

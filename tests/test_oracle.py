@@ -161,3 +161,19 @@ def test_libjpeg_loose_crosscheck():
         ref = np.asarray(PIL.open(io.BytesIO(data)).convert("RGB")).astype(int)
         d = np.abs(ref - oracle.decode(data).rgb.astype(int))
         assert d.mean() < 1.0 and (d <= 2).mean() > 0.999
+
+
+def test_one_component_frames():
+    """E6: a grayscale file codes the luma plane; its coefficients are the luma blocks of the 4:4:4 colour file
+    of the same content, and its pixels are R = G = B = the colour formula at Cb = Cr = 128."""
+    for (w, h, seed, ri) in [(100, 60, 5, 0), (64, 64, 6, 3), (9, 17, 7, 0)]:
+        g = oracle.decode(synth.encode(w, h, 0, 0, 90, 0, seed, ri))
+        c = oracle.decode(synth.encode(w, h, 1, 1, 90, 0, seed, ri))
+        assert g.qcoef.shape[0] * 3 == c.qcoef.shape[0]
+        assert np.array_equal(g.qcoef, c.qcoef[0::3]) and np.array_equal(g.dqcoef, c.dqcoef[0::3])
+        assert np.array_equal(g.rgb[..., 0], g.rgb[..., 1]) and np.array_equal(g.rgb[..., 0], g.rgb[..., 2])
+        # the luma value itself: IDCT of the block + 128, truncated and saturated
+        blk = g.dqcoef[0].astype(np.float32)
+        px = np.clip(np.trunc(oracle.idct(blk) + np.float32(128)), 0, 255).astype(np.uint8).reshape(8, 8)
+        hh, ww = min(8, h), min(8, w)
+        assert np.array_equal(g.rgb[:hh, :ww, 0], px[:hh, :ww])

@@ -820,10 +820,10 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
                     const uint32_t len = (e >> 8) & 31u, sz = e & 15u;
                     z2 = z + ((e >> 4) & 15u);                 // src/decoder.rs:225
                     const bool eob = (e & 255u) == 0;          // :212 (a pattern that is no code reads as 0 too)
-                    const uint32_t at = z2 < 64u ? z2 : 64u;   // :228 would index out of bounds at 64 and above
-                    row[eob ? 64u : at] = (int16_t)zj_value_ac(top << len, sz);
+                    // :228 would index out of bounds at 64 and above (slot 64 is spare).  An EOB or a ZRL
+                    // has no value bits, so what it stores is a zero into a slot that is zero anyway.
+                    row[z2 < 64u ? z2 : 64u] = (int16_t)zj_value_ac(top << len, sz);
                     const uint32_t adv = len + sz;
-                    p += adv;
                     z = z2 + 1u;                               // :230
                     o += adv;
                     const bool step = o >= 32u;
@@ -836,6 +836,9 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
                 };
                 if (use_canon) { while (turn(std::true_type{})) {} }
                 else { while (turn(std::false_type{})) {} }
+                // the reader's position in bits; when the block has just ended, its last symbol was not
+                // taken off the word offset (o wraps at 32), which the slot count makes up for
+                p = (wa + (uint32_t)(slot - col) / 64u) * 32u + o;
             }
             if (!__any(live)) break;
             if (live) {

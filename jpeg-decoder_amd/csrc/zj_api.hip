@@ -266,7 +266,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             s.first_win = (uint32_t)nwin_total;
             nwin_total += (uint64_t)nchunk * 64u * s.nc;
             s.first_tile = (uint32_t)tile_seg.size();
-            s.ntiles = (uint32_t)((s.raw_end - (s.raw_begin & ~15ull) + 16383u) / 16384u);
+            s.ntiles = (uint32_t)((s.raw_end - (s.raw_begin & ~15ull) + ZJ_UNSTUFF_TILE - 1u) / ZJ_UNSTUFF_TILE);
             if (s.ntiles == 0) s.ntiles = 1; // an empty segment still publishes its payload length
             for (uint32_t t = 0; t < s.ntiles; t++) tile_seg.push_back((uint32_t)b->segs.size());
             s.first_ptile = (uint32_t)ptile_seg.size();
@@ -317,8 +317,8 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.tile_seg = dev_upload(b, tile_seg);
     P.dtile_seg = dev_upload(b, dtile_seg);
     P.dtile_sum = dev_alloc<uint32_t>(b, dtile_seg.size() * 4, true);
-    P.tile_status = dev_alloc<uint64_t>(b, tile_seg.size() + 1, true);
-    P.tile_ticket = P.tile_status ? reinterpret_cast<uint32_t *>(P.tile_status + tile_seg.size()) : nullptr;
+    P.tile_status = dev_alloc<uint64_t>(b, tile_seg.size() + (b->segs.size() + 1) / 2 + 1, true);
+    P.seg_ticket = P.tile_status ? reinterpret_cast<uint32_t *>(P.tile_status + tile_seg.size()) : nullptr;
     std::vector<uint32_t> strip_grp_all, strip_img_all;
     for (int c = 0; c < ZJ_K2_CLASSES; c++) {
         b->L.k2_first[c] = (uint32_t)strip_grp_all.size();

@@ -84,7 +84,7 @@ struct ZjSegDev {
     uint32_t nc;                 // windows per subsequence = subbits / ZJ_WIN_BITS
     uint32_t first_win;          // offset of the segment's window records / window bases (64 * nc per chunk)
     uint32_t first_ptile;        // first workgroup of the position pass (256 windows each)
-    uint32_t first_tile, ntiles; // tiles of the unstuff pass (16 KiB of raw bytes each, from raw_begin & ~15)
+    uint32_t first_tile, ntiles; // tiles of the unstuff pass (15 KiB of raw bytes each, from raw_begin & ~15)
     uint32_t first_dtile, ndtiles; // tiles of the DC scan (256 MCUs each, at least one)
 };
 

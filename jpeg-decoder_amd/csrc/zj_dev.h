@@ -33,8 +33,8 @@ struct ZjParams {
     const uint32_t *dtile_seg;  // [DC-scan tile of 256 MCUs] segment
     uint32_t *dtile_sum;        // [DC-scan tile][4] per component: sum of the tile's differences, then of the tiles before it
     const uint32_t *tile_seg;   // [unstuff tile] segment
-    uint64_t *tile_status;      // [unstuff tile] look-back word: flag << 32 | bytes; [ntiles] is the ticket counter
-    uint32_t *tile_ticket;      // = (uint32_t *)&tile_status[ntiles]
+    uint64_t *tile_status;      // [unstuff tile] look-back word: flag << 32 | bytes
+    uint32_t *seg_ticket;       // [segment] next tile of the segment to hand out (stored behind tile_status)
     uint32_t *blockpos;         // [block] bit position of the block in its segment's stream
     int16_t *dcabs;             // [block] DC value after prediction
     uint8_t *dcbits;            // [block] bits of the DC symbol and its value (ZJ_DC_BAD: no code)
@@ -56,6 +56,7 @@ struct ZjParams {
 
 #define ZJ_K2_NS 4 // strips per workgroup of the IDCT/colour kernel
 #define ZJ_K2_CLASSES 5
+#define ZJ_UNSTUFF_TILE 15360u // raw bytes per workgroup of the unstuff pass: 256 threads x 15 words
 
 struct ZjLaunch {
     uint32_t nseg, nchunks, nblk256, nstrips, nk1w, nptiles, ntiles, ndtiles;

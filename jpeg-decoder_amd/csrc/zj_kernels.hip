@@ -208,55 +208,67 @@ __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *str
 
 // ---------------------------------------------------------------------------------- k0: unstuff
 // Drops every 00 that follows an FF (src/bitstream.rs:37-50) -- a stream compaction, done in one pass
-// over tiles of 16 KiB of raw bytes (256 threads x 64 bytes).  A tile counts its kept bytes, gets the
+// over tiles of 15 KiB of raw bytes (256 threads x 60 bytes).  A tile counts its kept bytes, gets the
 // number of bytes kept before it in the same segment from its predecessors (decoupled look-back: a
 // tile publishes its own count first and its inclusive prefix when known, and walks backwards over
 // the published words of the tiles before it), compacts into LDS and copies out in aligned 16-byte
-// pieces.  Tiles are taken in ticket order, so every tile a workgroup waits for is already running.
+// pieces.  Tiles of a segment are taken in ticket order, so every tile a workgroup waits for is already running.
+// A thread's share is 15 words, not 16: the runs of neighbouring lanes then start 15 banks apart, and
+// the 64 lanes of a wavefront that read or write word j of their runs touch 64 different LDS banks.
 // The unstuffed arena starts zeroed and the same bytes are written on every decode of a batch, so the
 // bytes behind a segment's payload stay zero (the reference pads with zeros, src/bitstream.rs:80-84).
-#define ZJ_K0_TILE 16384u
+#define ZJ_K0_WORDS 15u
+#define ZJ_K0_TILE (256u * ZJ_K0_WORDS * 4u) // must equal the tile size the batch planner uses
+static_assert(ZJ_K0_TILE == ZJ_UNSTUFF_TILE, "tile size of the unstuff pass");
 #define ZJ_TS_AGG (1ull << 32)
 #define ZJ_TS_INCL (2ull << 32)
 
 __global__ __launch_bounds__(256) void zj_k0_unstuff(ZjParams P)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t buf[ZJ_K0_TILE + 48];
+    __shared__ __attribute__((aligned(16))) uint8_t buf[ZJ_K0_TILE + 48]; // first the raw tile, then the compacted bytes
     __shared__ uint32_t wsum[8];
     __shared__ uint32_t s_tile, s_prefix;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) s_tile = atomicAdd(P.tile_ticket, 1u);
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    const uint32_t s = P.tile_seg[tile];
+    // The workgroup's segment is fixed by its index; which of the segment's tiles it takes is decided by a
+    // ticket per segment (one counter for the whole grid would serialise a quarter of a million atomics
+    // on one address).
+    const uint32_t s = P.tile_seg[blockIdx.x];
     const ZjSegDev sg = P.segs[s];
-    const uint32_t tj = tile - sg.first_tile;
+    if (tid == 0) s_tile = atomicAdd(&P.seg_ticket[s], 1u);
+    __syncthreads();
+    const uint32_t tj = s_tile;
+    const uint32_t tile = sg.first_tile + tj;
     const uint64_t a0 = sg.raw_begin & ~15ull;
-    const uint64_t my = a0 + (uint64_t)tj * ZJ_K0_TILE + (uint64_t)tid * 64u;
+    const uint64_t t0 = a0 + (uint64_t)tj * ZJ_K0_TILE;
+    const uint64_t my = t0 + (uint64_t)tid * (ZJ_K0_WORDS * 4u);
     const uint8_t *raw = P.raw;
 
-    uint32_t w[16];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
+    // the tile into LDS in 16-byte pieces (coalesced), then every thread picks up its 15 words
+    for (uint32_t pc = tid; pc < ZJ_K0_TILE / 16u; pc += 256u) {
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (my + 16u * i < sg.raw_end) v = *reinterpret_cast<const uint4 *>(raw + my + 16u * i);
-        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        if (t0 + 16u * pc < sg.raw_end) v = *reinterpret_cast<const uint4 *>(raw + t0 + 16u * pc);
+        reinterpret_cast<uint4 *>(buf)[pc] = v;
     }
-    // bytes of this thread that belong to the segment: [lo, hi) of 0..64 (signed differences, clamped)
+    __syncthreads();
+    uint32_t w[ZJ_K0_WORDS];
+#pragma unroll
+    for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) w[j] = reinterpret_cast<const uint32_t *>(buf)[tid * ZJ_K0_WORDS + j];
+    // bytes of this thread that belong to the segment: [lo, hi) of 0..60 (signed differences, clamped)
+    constexpr int NB = (int)(ZJ_K0_WORDS * 4u);
     const int64_t dlo = (int64_t)sg.raw_begin - (int64_t)my, dhi = (int64_t)sg.raw_end - (int64_t)my;
-    const uint32_t lo = dlo <= 0 ? 0u : (dlo >= 64 ? 64u : (uint32_t)dlo);
-    const uint32_t hi = dhi <= 0 ? 0u : (dhi >= 64 ? 64u : (uint32_t)dhi);
+    const uint32_t lo = dlo <= 0 ? 0u : (dlo >= NB ? (uint32_t)NB : (uint32_t)dlo);
+    const uint32_t hi = dhi <= 0 ? 0u : (dhi >= NB ? (uint32_t)NB : (uint32_t)dhi);
     uint32_t pf = 0; // is the byte before this thread's first byte an FF of the segment
     if (dlo < 0 && dhi >= 0) pf = raw[my - 1] == 0xFFu;
 
     // kill[j]: bit 7 of byte k set when byte 4j+k is not kept (a stuffed 00, or outside the segment)
-    uint32_t kill[16];
+    uint32_t kill[ZJ_K0_WORDS];
     uint32_t n;
-    if (__all(lo == 0u && hi == 64u)) {
+    if (__all(lo == 0u && hi == (uint32_t)NB)) {
         // whole wavefront inside the segment (all but the first and last tile): word-parallel byte tests
         uint32_t fprev = pf ? 0x80000000u : 0u, ndrop = 0;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) {
             const uint32_t x = w[j], y = ~x;
             const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); // bytes equal to 00
             const uint32_t f = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu); // bytes equal to FF
@@ -265,11 +277,11 @@ __global__ __launch_bounds__(256) void zj_k0_unstuff(ZjParams P)
             ndrop += __popc(kill[j]);
             fprev = f;
         }
-        n = 64u - ndrop;
+        n = (uint32_t)NB - ndrop;
     } else {
         uint64_t keep = 0;
 #pragma unroll
-        for (int k = 0; k < 64; k++) {
+        for (int k = 0; k < NB; k++) {
             const uint32_t byte = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
             const bool inr = (uint32_t)k >= lo && (uint32_t)k < hi;
             const bool drop = (byte == 0u) && pf;
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(256) void zj_k0_unstuff(ZjParams P)
             pf = inr && (byte == 0xFFu);
         }
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) {
             const uint32_t nib = (uint32_t)(keep >> (4 * j)) & 15u;
             const uint32_t spread = (nib | (nib << 7) | (nib << 14) | (nib << 21)) & 0x01010101u;
             kill[j] = (spread << 7) ^ 0x80808080u;
@@ -285,24 +297,38 @@ __global__ __launch_bounds__(256) void zj_k0_unstuff(ZjParams P)
         n = (uint32_t)__popcll(keep);
     }
     uint32_t total;
-    const uint32_t inc = block_incl_scan<4>(n, wsum, &total);
+    const uint32_t inc = block_incl_scan<4>(n, wsum, &total); // its barriers also end the reads of the raw tile
 
-    if (tid == 0) {
+    if (tid < 64u) {
+        // look-back by the first wavefront: 64 predecessors per step.  The nearest tile that has published
+        // an inclusive prefix ends the walk; every tile between it and this one must at least have
+        // published its own count, otherwise the step is repeated.
         uint32_t excl = 0;
         if (tj > 0) {
-            __hip_atomic_store(&P.tile_status[tile], ZJ_TS_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t j = tile - 1u;
+            if (tid == 0) __hip_atomic_store(&P.tile_status[tile], ZJ_TS_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t base = (int64_t)tile - 1;
             for (;;) {
-                const uint64_t sv = __hip_atomic_load(&P.tile_status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((sv >> 32) == 0) { __builtin_amdgcn_s_sleep(2); continue; }
-                excl += (uint32_t)sv;
-                if ((sv >> 32) == 2u) break; // inclusive prefix: everything before it is in
-                j--;                          // the first tile of a segment always publishes an inclusive prefix
+                const int64_t j = base - (int64_t)tid;
+                uint64_t sv = ZJ_TS_INCL; // in front of the segment's first tile: nothing, and final
+                if (j >= (int64_t)sg.first_tile) sv = __hip_atomic_load(&P.tile_status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t flag = (uint32_t)(sv >> 32);
+                const uint64_t incl = __ballot(flag == 2u), pending = __ballot(flag == 0u);
+                const uint32_t first = incl ? (uint32_t)__builtin_ctzll(incl) : 64u;
+                const uint64_t needed = first >= 63u ? ~0ull : ((2ull << first) - 1ull); // lanes 0..first
+                if (pending & needed) { __builtin_amdgcn_s_sleep(1); continue; }
+                uint32_t v = (tid <= first) ? (uint32_t)sv : 0u;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                excl += v;
+                if (first < 64u) break;
+                base -= 64;
             }
         }
-        __hip_atomic_store(&P.tile_status[tile], ZJ_TS_INCL | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_prefix = excl;
-        if (tile + 1u == sg.first_tile + sg.ntiles) P.seg_payload_bits[s] = (excl + total) * 8u;
+        if (tid == 0) {
+            __hip_atomic_store(&P.tile_status[tile], ZJ_TS_INCL | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = excl;
+            if (tile + 1u == sg.first_tile + sg.ntiles) P.seg_payload_bits[s] = (excl + total) * 8u;
+        }
     }
     __syncthreads();
     const uint32_t prefix = s_prefix;
@@ -313,12 +339,12 @@ __global__ __launch_bounds__(256) void zj_k0_unstuff(ZjParams P)
         // executed in order); only a thread's last byte has no successor and goes to a spare slot
         uint32_t o = shift + inc - n;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t dead = (kill[j] >> (8 * k + 7)) & 1u;
-                const uint32_t at = (j == 15 && k == 3 && dead) ? ZJ_K0_TILE + 32u : o;
-                buf[at] = (uint8_t)(w[j] >> (8 * k));
+            for (uint32_t k = 0; k < 4u; k++) {
+                const uint32_t dead = (kill[j] >> (8u * k + 7u)) & 1u;
+                const uint32_t at = (j == ZJ_K0_WORDS - 1u && k == 3u && dead) ? ZJ_K0_TILE + 32u : o;
+                buf[at] = (uint8_t)(w[j] >> (8u * k));
                 o += 1u - dead;
             }
         }
@@ -1287,7 +1313,7 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     int e = 0;
     if (ev) hipEventRecord(ev[e++], st);
     hipMemsetAsync(P.flags, 0, 16, st);
-    hipMemsetAsync(P.tile_status, 0, ((size_t)L.ntiles + 1u) * sizeof(uint64_t), st);
+    hipMemsetAsync(P.tile_status, 0, (size_t)L.ntiles * sizeof(uint64_t) + (size_t)L.nseg * sizeof(uint32_t), st); // look-back words and the tickets behind them
     if (L.ntiles) hipLaunchKernelGGL(zj_k0_unstuff, dim3(L.ntiles), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1a_sync, dim3(L.nchunks / 4), dim3(256), 0, st, P);

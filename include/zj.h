@@ -141,6 +141,9 @@ const char *zj_last_error(zj_ctx *ctx);
 /* Testing aid: build the lookup tables without their second level, so that every code longer than the
  * first level goes through the canonical search (the path that otherwise only unusual tables reach). */
 #define ZJ_FLAG_NO_SECOND_LEVEL 0x1000000u
+/* Testing aid: list the restart intervals with the host loop (zj_restart_offsets) instead of the
+ * marker search on the device that zj_batch_create otherwise runs over the uploaded scans. */
+#define ZJ_FLAG_HOST_MARKER_SCAN 0x2000000u
 
 /* Plan a batch: validates the images, builds the device tables, uploads the scans, allocates all
  * scratch and the coefficient arena.  Everything the decode call needs is resident in HBM when
@@ -164,6 +167,12 @@ int zj_batch_finish(zj_batch *b, uint32_t *status);
 const int16_t *zj_batch_qcoef(zj_batch *b, size_t i);
 /* Copy image i's coefficients out: zig-zag quantised and/or natural-order dequantised. */
 int zj_batch_export_coef(zj_batch *b, size_t i, int16_t *qcoef, int16_t *dqcoef, int mem);
+
+/* The entropy-coded segments (restart intervals, the defined extension for FFDD/RSTn; one segment
+ * when the image has no restart interval) the planner cut image i into: ranges[2k], ranges[2k+1] =
+ * begin and end byte offset of segment k relative to img->scan, RSTn markers excluded.  Writes at
+ * most `cap` pairs, returns the number of segments (0 for an unsupported image). */
+size_t zj_batch_segments(zj_batch *b, size_t i, uint64_t *ranges, size_t cap);
 
 /* Per-kernel timing: when enabled, zj_batch_decode brackets every kernel with events on the
  * context's stream; zj_batch_kernel_times waits and returns milliseconds of the last decode call

@@ -13,6 +13,7 @@ ZJ_OK, ZJ_E_INVALID, ZJ_E_FORMAT, ZJ_E_UNSUPPORTED, ZJ_E_DEVICE, ZJ_E_NOMEM, ZJ_
 ZJ_ST_BAD_CODE, ZJ_ST_COEF_OVERFLOW, ZJ_ST_TRUNCATED, ZJ_ST_UNSUPPORTED = 1, 2, 4, 8
 ZJ_MEM_HOST, ZJ_MEM_DEVICE = 0, 1
 ZJ_FLAG_NO_SECOND_LEVEL = 0x1000000
+ZJ_FLAG_HOST_MARKER_SCAN = 0x2000000
 ZJ_NUM_KERNELS = 9
 
 
@@ -54,6 +55,7 @@ _EXPORTS = [
     "zj_device_count", "zj_create", "zj_destroy", "zj_last_error",
     "zj_batch_create", "zj_batch_destroy", "zj_batch_decode", "zj_batch_finish", "zj_batch_qcoef",
     "zj_batch_export_coef", "zj_batch_set_profiling", "zj_batch_kernel_times", "zj_kernel_name", "zj_batch_bytes",
+    "zj_batch_segments",
     "zj_decode_batch",
 ]
 
@@ -94,6 +96,7 @@ def lib():
     L.zj_batch_kernel_times.argtypes = [vp, C.POINTER(C.c_float)]; L.zj_batch_kernel_times.restype = C.c_int
     L.zj_kernel_name.argtypes = [C.c_int]; L.zj_kernel_name.restype = C.c_char_p
     L.zj_batch_bytes.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4; L.zj_batch_bytes.restype = C.c_int
+    L.zj_batch_segments.argtypes = [vp, sz, C.POINTER(C.c_uint64), sz]; L.zj_batch_segments.restype = sz
     L.zj_decode_batch.argtypes = [vp, C.POINTER(zj_image), sz, C.POINTER(zj_output), u32p]; L.zj_decode_batch.restype = C.c_int
     _lib = L
     return L

@@ -109,6 +109,69 @@ static T *dev_upload(zj_batch *b, const std::vector<T> &v)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Restart markers of every image that has a restart interval, searched on the device in the uploaded
+// scans.  mark_first[i] = index of image i in the lists (ZJ_NONE: no restart interval); per listed image
+// the number of markers found and where its offsets begin in `offs` (at most one per restart interval of
+// the frame is kept).  The device buffers used live only for the duration of the call.
+static bool find_markers(zj_batch *b, const zj_image *images, size_t n, const uint8_t *raw, const std::vector<size_t> &raw_off,
+                         std::vector<uint32_t> &mark_first, std::vector<uint32_t> &count, std::vector<uint32_t> &outfirst,
+                         std::vector<uint32_t> &offs)
+{
+    zj_ctx *ctx = b->ctx;
+    std::vector<ZjMarkImg> mi;
+    std::vector<uint32_t> tile_img;
+    uint64_t nout = 0;
+    for (size_t i = 0; i < n; i++) {
+        const zj_image &im = images[i];
+        if (!zj_image_supported(&im) || im.restart_interval == 0) continue;
+        ZjMarkImg d;
+        memset(&d, 0, sizeof d);
+        d.raw_off = raw_off[i];
+        d.scan_len = (uint32_t)im.scan_len;
+        d.first_tile = (uint32_t)tile_img.size();
+        d.ntiles = (uint32_t)((im.scan_len + ZJ_MARK_TILE - 1) / ZJ_MARK_TILE);
+        d.out_first = (uint32_t)nout;
+        d.cap = (zj_image_mcus(&im) + im.restart_interval - 1) / im.restart_interval;
+        nout += d.cap;
+        if (nout > 0xF0000000ull || tile_img.size() + d.ntiles > 0xF0000000ull) { ctx->err = "batch too large for 32-bit indices"; return false; }
+        mark_first[i] = (uint32_t)mi.size();
+        for (uint32_t t = 0; t < d.ntiles; t++) tile_img.push_back((uint32_t)mi.size());
+        outfirst.push_back(d.out_first);
+        mi.push_back(d);
+    }
+    count.assign(mi.size(), 0);
+    offs.assign((size_t)nout, 0);
+    if (mi.empty() || tile_img.empty()) return true;
+    ZjMarkParams M;
+    memset(&M, 0, sizeof M);
+    M.raw = raw;
+    M.nimgs = (uint32_t)mi.size();
+    M.ntiles = (uint32_t)tile_img.size();
+    void *d_imgs = nullptr, *d_tile_img = nullptr, *d_tile_count = nullptr, *d_img_count = nullptr, *d_offs = nullptr;
+    hipStream_t st = ctx->stream;
+    bool ok = hip_ok(ctx, hipMalloc(&d_imgs, mi.size() * sizeof(ZjMarkImg)), "hipMalloc") &&
+              hip_ok(ctx, hipMalloc(&d_tile_img, tile_img.size() * 4), "hipMalloc") &&
+              hip_ok(ctx, hipMalloc(&d_tile_count, tile_img.size() * 4), "hipMalloc") &&
+              hip_ok(ctx, hipMalloc(&d_img_count, mi.size() * 4), "hipMalloc") &&
+              hip_ok(ctx, hipMalloc(&d_offs, (size_t)(nout + 1) * 4), "hipMalloc");
+    if (ok) ok = hip_ok(ctx, hipMemcpyAsync(d_imgs, mi.data(), mi.size() * sizeof(ZjMarkImg), hipMemcpyHostToDevice, st), "H2D marker images") &&
+                 hip_ok(ctx, hipMemcpyAsync(d_tile_img, tile_img.data(), tile_img.size() * 4, hipMemcpyHostToDevice, st), "H2D marker tiles");
+    if (ok) {
+        M.imgs = (const ZjMarkImg *)d_imgs;
+        M.tile_img = (const uint32_t *)d_tile_img;
+        M.tile_count = (uint32_t *)d_tile_count;
+        M.img_count = (uint32_t *)d_img_count;
+        M.offs = (uint32_t *)d_offs;
+        zj_launch_markers(M, st);
+        ok = hip_ok(ctx, hipGetLastError(), "marker kernels") &&
+             hip_ok(ctx, hipMemcpyAsync(count.data(), d_img_count, mi.size() * 4, hipMemcpyDeviceToHost, st), "D2H marker counts") &&
+             (nout == 0 || hip_ok(ctx, hipMemcpyAsync(offs.data(), d_offs, (size_t)nout * 4, hipMemcpyDeviceToHost, st), "D2H marker offsets")) &&
+             hip_ok(ctx, hipStreamSynchronize(st), "sync after marker search");
+    }
+    (void)hipFree(d_imgs); (void)hipFree(d_tile_img); (void)hipFree(d_tile_count); (void)hipFree(d_img_count); (void)hipFree(d_offs);
+    return ok;
+}
+
 extern "C" void zj_batch_destroy(zj_batch *b)
 {
     if (!b) return;
@@ -164,6 +227,31 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     size_t raw_total = 0, ust_total = 0;
     uint64_t nsub_total = 0, nblk_total = 0, nstrip_total = 0;
     std::vector<size_t> offs;
+
+    // The scans go to the device first: the restart markers are searched there.
+    for (size_t i = 0; i < n; i++) {
+        if (!zj_image_supported(&images[i])) continue;
+        raw_off[i] = raw_total;
+        raw_total += align_up(images[i].scan_len, 16) + 16;
+    }
+    uint8_t *raw = dev_alloc<uint8_t>(b, raw_total + 1040, false);
+    if (!raw) { zj_batch_destroy(b); return nullptr; }
+    {
+        // the entropy-coded bytes as stored, each image at a 16-byte aligned offset
+        bool up = hip_ok(ctx, hipMemsetAsync(raw, 0, raw_total + 1040, ctx->stream), "hipMemset");
+        for (size_t i = 0; up && i < n; i++) {
+            if (!zj_image_supported(&images[i]) || images[i].scan_len == 0) continue;
+            up = hip_ok(ctx, hipMemcpyAsync(raw + raw_off[i], images[i].scan, images[i].scan_len, hipMemcpyHostToDevice, ctx->stream),
+                        "hipMemcpy scan");
+        }
+        if (up) up = hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync after upload");
+        if (!up) { zj_batch_destroy(b); return nullptr; }
+    }
+    std::vector<uint32_t> mark_first(n, ZJ_NONE), mark_count, mark_outfirst, mark_offs; // device-found restart offsets per image
+    if (!(flags & ZJ_FLAG_HOST_MARKER_SCAN) && !find_markers(b, images, n, raw, raw_off, mark_first, mark_count, mark_outfirst, mark_offs)) {
+        zj_batch_destroy(b);
+        return nullptr;
+    }
 
     for (size_t i = 0; i < n; i++) {
         const zj_image &im = images[i];
@@ -229,15 +317,20 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
         }
         // segments: one per restart interval (src/bitstream.rs:41-47 ends the reference's stream at
         // the first RSTn; here every interval is an independent segment)
-        raw_off[i] = raw_total;
-        raw_total += align_up(im.scan_len, 16) + 16;
         const uint32_t ri = im.restart_interval;
         const uint64_t nseg = ri ? (nmcu + ri - 1) / ri : 1;
         d.ri_blocks = ri ? ri * d.bpm : 0;
         d.nseg = (uint32_t)nseg;
         size_t nint = 1;
         offs.assign(1, 0);
-        if (ri) {
+        if (ri && mark_first[i] != ZJ_NONE) {
+            // found on the device: entry k is the byte behind the k-th RSTn, as zj_restart_offsets lists them
+            const uint32_t mi = mark_first[i];
+            const size_t have = std::min<size_t>(mark_count[mi], (size_t)nseg);
+            offs.resize(1 + have);
+            for (size_t k = 0; k < have; k++) offs[1 + k] = mark_offs[mark_outfirst[mi] + k];
+            nint = 1 + have;
+        } else if (ri) {
             offs.resize((size_t)nseg + 1);
             nint = zj_restart_offsets(&im, offs.data(), offs.size());
             if (nint > offs.size()) nint = offs.size();
@@ -335,7 +428,6 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.wluts = dev_upload(b, wluts);
     P.canons = dev_upload(b, canons);
     P.qts = dev_upload(b, qts);
-    uint8_t *raw = dev_alloc<uint8_t>(b, raw_total + 1040, false);
     P.raw = raw;
     P.ust = dev_alloc<uint8_t>(b, ust_total + 1040, true);
     P.seg_payload_bits = dev_alloc<uint32_t>(b, b->segs.size(), true);
@@ -360,16 +452,6 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     if (ok) ok = hip_ok(ctx, hipHostMalloc((void **)&b->h_rgb, (n ? n : 1) * sizeof(uint8_t *), hipHostMallocDefault), "hipHostMalloc") &&
                  hip_ok(ctx, hipHostMalloc((void **)&b->h_stride, (n ? n : 1) * sizeof(size_t), hipHostMallocDefault), "hipHostMalloc") &&
                  hip_ok(ctx, hipHostMalloc((void **)&b->h_flags, 16, hipHostMallocDefault), "hipHostMalloc");
-    if (ok) {
-        // upload the scans: the entropy-coded bytes as stored, each image at a 16-byte aligned offset
-        ok = hip_ok(ctx, hipMemsetAsync(raw, 0, raw_total + 1040, ctx->stream), "hipMemset");
-        for (size_t i = 0; ok && i < n; i++) {
-            if (b->unsupported[i] || images[i].scan_len == 0) continue;
-            ok = hip_ok(ctx, hipMemcpyAsync(raw + raw_off[i], images[i].scan, images[i].scan_len, hipMemcpyHostToDevice, ctx->stream),
-                        "hipMemcpy scan");
-        }
-        if (ok) ok = hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync after upload");
-    }
     if (!ok) { zj_batch_destroy(b); return nullptr; }
     b->L.nseg = (uint32_t)b->segs.size();
     b->L.nchunks = P.nchunks;
@@ -485,6 +567,18 @@ extern "C" int zj_batch_export_coef(zj_batch *b, size_t i, int16_t *qcoef, int16
     }
     if (!hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
     return ZJ_OK;
+}
+
+extern "C" size_t zj_batch_segments(zj_batch *b, size_t i, uint64_t *ranges, size_t cap)
+{
+    if (!b || i >= b->n || b->unsupported[i]) return 0;
+    const ZjImgDev &d = b->imgs[i];
+    const uint64_t base = d.nseg ? b->segs[d.first_seg].raw_begin : 0; // the first segment starts at the scan's first byte
+    for (uint32_t k = 0; k < d.nseg && k < cap; k++) {
+        ranges[2 * (size_t)k] = b->segs[d.first_seg + k].raw_begin - base;
+        ranges[2 * (size_t)k + 1] = b->segs[d.first_seg + k].raw_end - base;
+    }
+    return d.nseg;
 }
 
 extern "C" int zj_batch_set_profiling(zj_batch *b, int enable)

@@ -64,7 +64,29 @@ struct ZjLaunch {
     int fix_iters;
 };
 
+// Restart-marker search over the uploaded scans (batch planning): one entry per image that has a restart interval.
+#define ZJ_MARK_TILE 16384u // scan bytes per workgroup: 256 threads x 64 bytes
+struct ZjMarkImg {
+    uint64_t raw_off;    // the image's scan inside the raw arena (16-byte aligned)
+    uint32_t scan_len;
+    uint32_t first_tile; // of this image in the tile list
+    uint32_t ntiles;
+    uint32_t out_first;  // first entry of this image in `offs`
+    uint32_t cap;        // markers wanted (restart intervals of the frame); later ones are counted only
+    uint32_t pad;
+};
+struct ZjMarkParams {
+    const uint8_t *raw;
+    const ZjMarkImg *imgs;
+    const uint32_t *tile_img; // [tile] index into imgs
+    uint32_t *tile_count;     // [tile] markers in the tile, then (after the scan) markers of the image before the tile
+    uint32_t *img_count;      // [image] markers found
+    uint32_t *offs;           // per image: scan offset of the byte after its k-th marker
+    uint32_t nimgs, ntiles;
+};
+
 extern "C" {
+void zj_launch_markers(const ZjMarkParams &M, hipStream_t st);
 void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream_t st, hipEvent_t *ev);
 void zj_launch_fix_only(const ZjParams &P, const ZjLaunch &L, hipStream_t st);
 void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipStream_t st);

@@ -126,14 +126,14 @@ extern "C" int zj_parse(const uint8_t *file, size_t len, zj_parsed *out)
             size_t p = r.pos;
             uint32_t nrst = 0;
             while (p + 1 < len) {
-                if (file[p] == 0xff) {
-                    const uint8_t x = file[p + 1];
-                    if (x == 0x00) { p += 2; continue; }
-                    if (x >= 0xd0 && x <= 0xd7) { nrst++; p += 2; continue; }
-                    if (x == 0xff) { p += 1; continue; }
-                    break;
-                }
-                p++;
+                const uint8_t *ff = (const uint8_t *)memchr(file + p, 0xff, len - 1 - p); // only FF bytes matter
+                if (!ff) { p = len; break; }
+                p = (size_t)(ff - file);
+                const uint8_t x = file[p + 1];
+                if (x == 0x00) { p += 2; continue; }
+                if (x >= 0xd0 && x <= 0xd7) { nrst++; p += 2; continue; }
+                if (x == 0xff) { p += 1; continue; }
+                break;
             }
             if (p + 1 >= len) p = len;
             im.scan = file + r.pos;
@@ -186,12 +186,17 @@ extern "C" size_t zj_restart_offsets(const zj_image *im, size_t *offsets, size_t
     if (n < cap) offsets[n] = 0;
     n++;
     const uint8_t *s = im->scan;
-    for (size_t p = 0; p + 1 < im->scan_len; p++) {
-        if (s[p] == 0xff && s[p + 1] >= 0xd0 && s[p + 1] <= 0xd7) {
+    size_t p = 0;
+    while (p + 1 < im->scan_len) {
+        const uint8_t *ff = (const uint8_t *)memchr(s + p, 0xff, im->scan_len - 1 - p);
+        if (!ff) break;
+        p = (size_t)(ff - s);
+        if (s[p + 1] >= 0xd0 && s[p + 1] <= 0xd7) {
             if (n < cap) offsets[n] = p + 2;
             n++;
             p++;
         }
+        p++;
     }
     return n;
 }

@@ -8,8 +8,7 @@
 //                subsequences until their state meets the recorded one (self-synchronisation)
 //   k1b_fix      stitches consecutive wavefront chunks the same way, one lane per chunk boundary
 //   k1s_scan     exclusive prefix sum of blocks-per-subsequence inside each segment
-//   k1i_index    second walk from the now-known states: where every block begins; verifies the
-//                chain of recorded states
+//   k1p_positions  turns the block-start bitmap left by the walks into the list of block positions
 //   k1d_dcscan   DC differences from the block positions, DC predictor = wrapping-i16 prefix sum per
 //                component                                                  (src/decoder.rs:194-200)
 //   k1w_write    one lane per block: decode the block into an LDS tile, store 64 blocks coalesced
@@ -1291,6 +1290,83 @@ __global__ __launch_bounds__(256) void zj_k2_idct_gray(ZjParams P, uint32_t firs
     }
 }
 
+// ---------------------------------------------------------------------------------- restart markers (planning)
+// Where the restart intervals of an image begin: every position p of the scan with byte p = FF and byte
+// p+1 = D0..D7 (src/bitstream.rs:41-47 stops at such a pair; the reference has no restart support, the
+// intervals are the defined extension).  An ordered stream compaction in three launches: markers per tile
+// of 16 KiB, exclusive scan of the tile counts per image, then the same search again writing the offsets.
+// A thread owns 64 bytes and builds a 64-bit marker mask with word-parallel byte tests.
+__device__ __forceinline__ uint64_t zj_marker_mask(const ZjMarkParams &M, const ZjMarkImg &d, uint32_t p0)
+{
+    if (p0 + 1u >= d.scan_len) return 0;
+    const uint8_t *src = M.raw + d.raw_off + p0;
+    uint32_t w[17];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint4 v = reinterpret_cast<const uint4 *>(src)[q];
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+    w[16] = reinterpret_cast<const uint32_t *>(src)[16]; // the arena has slack behind the last scan
+    uint32_t ff[16], dx[17];
+#pragma unroll
+    for (int j = 0; j < 17; j++) {
+        const uint32_t y = ~w[j], x = (w[j] ^ 0xD0D0D0D0u) & 0xF8F8F8F8u;
+        if (j < 16) ff[j] = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu); // bytes equal to FF
+        dx[j] = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);             // bytes D0..D7
+    }
+    uint64_t mask = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t m = ff[j] & __builtin_amdgcn_alignbyte(dx[j + 1], dx[j], 1); // FF followed by D0..D7
+        const uint32_t nib = ((((m >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 15u;
+        mask |= (uint64_t)nib << (4 * j);
+    }
+    // only pairs that lie inside the scan: p + 1 < scan_len
+    const uint32_t nvalid = d.scan_len - 1u - p0;
+    if (nvalid < 64u) mask &= (1ull << nvalid) - 1ull;
+    return mask;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void zj_km_markers(ZjMarkParams M)
+{
+    __shared__ uint32_t wsum[8];
+    const ZjMarkImg d = M.imgs[M.tile_img[blockIdx.x]];
+    const uint32_t p0 = (blockIdx.x - d.first_tile) * ZJ_MARK_TILE + threadIdx.x * 64u;
+    uint64_t mask = zj_marker_mask(M, d, p0);
+    const uint32_t n = (uint32_t)__popcll(mask);
+    uint32_t total;
+    const uint32_t inc = block_incl_scan<4>(n, wsum, &total);
+    if (!WRITE) {
+        if (threadIdx.x == 0) M.tile_count[blockIdx.x] = total;
+    } else {
+        uint32_t k = M.tile_count[blockIdx.x] + inc - n;
+        while (mask && k < d.cap) {
+            const uint32_t bit = (uint32_t)__builtin_ctzll(mask);
+            M.offs[d.out_first + k] = p0 + bit + 2u;
+            mask &= mask - 1ull;
+            k++;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void zj_km_scan(ZjMarkParams M)
+{
+    __shared__ uint32_t wsum[8];
+    const ZjMarkImg d = M.imgs[blockIdx.x];
+    uint32_t run = 0;
+    for (uint32_t t0 = 0; t0 < d.ntiles; t0 += 256u) { // uniform trip count
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t v = t < d.ntiles ? M.tile_count[d.first_tile + t] : 0u;
+        uint32_t total;
+        const uint32_t inc = block_incl_scan<4>(v, wsum, &total);
+        if (t < d.ntiles) M.tile_count[d.first_tile + t] = run + inc - v;
+        run += total;
+        __syncthreads(); // wsum is reused by the next round
+    }
+    if (threadIdx.x == 0) M.img_count[blockIdx.x] = run;
+}
+
 // ---------------------------------------------------------------------------------- export (tests)
 // dqcoef[b][nat] = qcoef[b][zz] * q[zz]: the reference's `blocks` entry (src/decoder.rs:237-240).
 __global__ __launch_bounds__(256) void zj_kx_dequant(ZjParams P, uint32_t ii, int16_t *dst)
@@ -1333,6 +1409,14 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
+}
+
+extern "C" void zj_launch_markers(const ZjMarkParams &M, hipStream_t st)
+{
+    if (!M.ntiles) return;
+    hipLaunchKernelGGL(zj_km_markers<false>, dim3(M.ntiles), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(zj_km_scan, dim3(M.nimgs), dim3(256), 0, st, M);
+    hipLaunchKernelGGL(zj_km_markers<true>, dim3(M.ntiles), dim3(256), 0, st, M);
 }
 
 extern "C" void zj_launch_fix_only(const ZjParams &P, const ZjLaunch &L, hipStream_t st)

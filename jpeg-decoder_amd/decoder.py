@@ -55,6 +55,13 @@ class ParsedImage:
     def nblocks(self):
         return B.lib().zj_image_blocks(C.byref(self.parsed.image))
 
+    def restart_offsets(self):
+        """Byte offsets inside the scan at which restart intervals begin (zj_restart_offsets, the host loop)."""
+        n = B.lib().zj_restart_offsets(C.byref(self.parsed.image), None, 0)
+        buf = (C.c_size_t * max(n, 1))()
+        B.lib().zj_restart_offsets(C.byref(self.parsed.image), buf, n)
+        return [int(buf[k]) for k in range(n)]
+
     def band(self, row0, nrows):
         """Sub-image of MCU rows [row0, row0+nrows) of a restart-marked image (zj_image_band)."""
         out = BandImage(self)
@@ -196,6 +203,13 @@ class Batch:
         v = [C.c_uint64() for _ in range(4)]
         B.lib().zj_batch_bytes(self.h, *[C.byref(x) for x in v])
         return {"scan": v[0].value, "coef": v[1].value, "rgb": v[2].value, "pixels": v[3].value}
+
+    def segments(self, i):
+        """(begin, end) byte offsets inside image i's scan of the entropy-coded segments it was cut into."""
+        n = B.lib().zj_batch_segments(self.h, i, None, 0)
+        buf = (C.c_uint64 * max(2 * n, 1))()
+        B.lib().zj_batch_segments(self.h, i, buf, n)
+        return [(int(buf[2 * k]), int(buf[2 * k + 1])) for k in range(n)]
 
     def close(self):
         if self.h:

@@ -187,6 +187,60 @@ def test_restart_band_equals_rows_of_full_decode(ctx):
     assert np.array_equal(got, full)
 
 
+def test_device_marker_search_equals_host_loop(ctx):
+    """The planner finds the restart markers on the device; the segments it cuts must be those of the host
+    loop (zj_restart_offsets) -- on clean files and on scans with markers planted at tile and thread
+    boundaries of the search, behind fill bytes (FF FF Dn), at the very end, too many and too few."""
+    rng = np.random.default_rng(7)
+    base = synth.encode(768, 512, 2, 2, 92, 2, 41, 4)
+    info = oracle.probe(base)
+    assert info.scan_len > 5 * 16384
+    files = [base, synth.encode(200, 120, 1, 1, 90, 0, 42, 1), synth.encode(320, 240, 2, 1, 90, 0, 43, 7), synth.encode(64, 64, 2, 2, 90, 0, 44, 0)]
+
+    def plant(d, at, fill=False):
+        at += info.scan_off
+        if fill:
+            d[at - 1] = 0xFF
+        d[at] = 0xFF
+        d[at + 1] = 0xD0 + int(rng.integers(0, 8))
+
+    d = bytearray(base)
+    for at in (16383, 16384, 16382, 2 * 16384 - 1, 63, 64, 127, 4095, 4096, info.scan_len - 2, info.scan_len - 3):
+        plant(d, at)
+    plant(d, 3 * 16384 + 1, fill=True)
+    plant(d, 70000, fill=True)
+    files.append(bytes(d))
+    d = bytearray(base)  # far more markers than intervals
+    for at in rng.integers(2, info.scan_len - 4, 3000):
+        plant(d, int(at))
+    files.append(bytes(d))
+    d = bytearray(base)  # markers removed: fewer than intervals
+    for k in range(info.scan_off, info.scan_off + info.scan_len - 1):
+        if d[k] == 0xFF and 0xD0 <= d[k + 1] <= 0xD7 and rng.integers(0, 3):
+            d[k + 1] = 0x00
+    files.append(bytes(d))
+    files.append(base[: info.scan_off + 40000] + b"\xff")  # ends in a lone FF
+    imgs = [J.ParsedImage(f) for f in files]
+    seg = {}
+    for flag in (0, B.ZJ_FLAG_HOST_MARKER_SCAN):
+        b = J.Batch(ctx, imgs, flag)
+        outs = b.alloc_rgb()
+        b.decode(outs)
+        st = b.finish()
+        seg[flag] = ([b.segments(i) for i in range(len(imgs))], st.copy(), [o[:, : im.width * 3].cpu().numpy() for o, im in zip(outs, imgs)])
+        b.close()
+    dev, host = seg[0], seg[B.ZJ_FLAG_HOST_MARKER_SCAN]
+    for i in range(len(imgs)):
+        assert dev[0][i] == host[0][i], f"segments of image {i}"
+        if dev[1][i] == 0:  # blocks that a damaged stream does not reach are not written
+            assert np.array_equal(dev[2][i], host[2][i])
+    assert np.array_equal(dev[1], host[1])
+    assert not dev[1][:4].any()
+    p0 = imgs[0]
+    offs = p0.restart_offsets()
+    assert [s[0] for s in dev[0][0]] == offs[: len(dev[0][0])]
+
+
 def test_corrupt_streams_set_status_not_faults(ctx):
     """Malformed entropy data: the reference panics (src/decoder.rs:194-228, src/ec.rs:27,47); the GPU
     path must return status bits and never fault."""

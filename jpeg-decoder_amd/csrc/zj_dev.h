@@ -56,7 +56,7 @@ struct ZjParams {
 
 #define ZJ_K2_NS 4 // strips per workgroup of the IDCT/colour kernel
 #define ZJ_K2_CLASSES 5
-#define ZJ_UNSTUFF_TILE 15360u // raw bytes per workgroup of the unstuff pass: 256 threads x 15 words
+#define ZJ_UNSTUFF_TILE 15872u // raw bytes per workgroup of the unstuff pass: 128 threads x 31 words
 
 struct ZjLaunch {
     uint32_t nseg, nchunks, nblk256, nstrips, nk1w, nptiles, ntiles, ndtiles;

@@ -207,24 +207,29 @@ __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *str
 
 // ---------------------------------------------------------------------------------- k0: unstuff
 // Drops every 00 that follows an FF (src/bitstream.rs:37-50) -- a stream compaction, done in one pass
-// over tiles of 15 KiB of raw bytes (256 threads x 60 bytes).  A tile counts its kept bytes, gets the
+// over tiles of 15.5 KiB of raw bytes (128 threads x 124 bytes).  A tile counts its kept bytes, gets the
 // number of bytes kept before it in the same segment from its predecessors (decoupled look-back: a
 // tile publishes its own count first and its inclusive prefix when known, and walks backwards over
-// the published words of the tiles before it), compacts into LDS and copies out in aligned 16-byte
-// pieces.  Tiles of a segment are taken in ticket order, so every tile a workgroup waits for is already running.
-// A thread's share is 15 words, not 16: the runs of neighbouring lanes then start 15 banks apart, and
-// the 64 lanes of a wavefront that read or write word j of their runs touch 64 different LDS banks.
+// the published words of the tiles before it), compacts into LDS while it waits for them, and copies out
+// in aligned 16-byte pieces.  Tiles of a segment are taken in ticket order, so every tile a workgroup waits for is already running.
+// The pass is bound by the latency of its dependent steps (ticket, load, publish, look-back, store), so
+// what counts is the number of tiles a CU holds at once: LDS allows ten of this size, and two wavefronts
+// per tile keep the wavefront slots from running out first.
+// A thread's share is 31 words, an odd number: the runs of neighbouring lanes then start 31 banks apart,
+// and the 64 lanes of a wavefront that read or write word j of their runs touch every LDS bank twice.
 // The unstuffed arena starts zeroed and the same bytes are written on every decode of a batch, so the
 // bytes behind a segment's payload stay zero (the reference pads with zeros, src/bitstream.rs:80-84).
-#define ZJ_K0_WORDS 15u
-#define ZJ_K0_TILE (256u * ZJ_K0_WORDS * 4u) // must equal the tile size the batch planner uses
+#define ZJ_K0_THREADS 128
+#define ZJ_K0_WORDS 31u
+#define ZJ_K0_TILE ((uint32_t)ZJ_K0_THREADS * ZJ_K0_WORDS * 4u) // must equal the tile size the batch planner uses
 static_assert(ZJ_K0_TILE == ZJ_UNSTUFF_TILE, "tile size of the unstuff pass");
+#define ZJ_K0_PAD 16u // the compacted bytes begin here in the LDS buffer
 #define ZJ_TS_AGG (1ull << 32)
 #define ZJ_TS_INCL (2ull << 32)
 
-__global__ __launch_bounds__(256) void zj_k0_unstuff(ZjParams P)
+__global__ __launch_bounds__(ZJ_K0_THREADS) void zj_k0_unstuff(ZjParams P)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t buf[ZJ_K0_TILE + 48]; // first the raw tile, then the compacted bytes
+    __shared__ __attribute__((aligned(16))) uint8_t buf[ZJ_K0_TILE + ZJ_K0_PAD + 64]; // first the raw tile, then the compacted bytes
     __shared__ uint32_t wsum[8];
     __shared__ uint32_t s_tile, s_prefix;
     const uint32_t tid = threadIdx.x;
@@ -242,8 +247,8 @@ __global__ __launch_bounds__(256) void zj_k0_unstuff(ZjParams P)
     const uint64_t my = t0 + (uint64_t)tid * (ZJ_K0_WORDS * 4u);
     const uint8_t *raw = P.raw;
 
-    // the tile into LDS in 16-byte pieces (coalesced), then every thread picks up its 15 words
-    for (uint32_t pc = tid; pc < ZJ_K0_TILE / 16u; pc += 256u) {
+    // the tile into LDS in 16-byte pieces (coalesced), then every thread picks up its words
+    for (uint32_t pc = tid; pc < ZJ_K0_TILE / 16u; pc += ZJ_K0_THREADS) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (t0 + 16u * pc < sg.raw_end) v = *reinterpret_cast<const uint4 *>(raw + t0 + 16u * pc);
         reinterpret_cast<uint4 *>(buf)[pc] = v;
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(256) void zj_k0_unstuff(ZjParams P)
     uint32_t w[ZJ_K0_WORDS];
 #pragma unroll
     for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) w[j] = reinterpret_cast<const uint32_t *>(buf)[tid * ZJ_K0_WORDS + j];
-    // bytes of this thread that belong to the segment: [lo, hi) of 0..60 (signed differences, clamped)
+    // bytes of this thread that belong to the segment: [lo, hi) of 0..NB (signed differences, clamped)
     constexpr int NB = (int)(ZJ_K0_WORDS * 4u);
     const int64_t dlo = (int64_t)sg.raw_begin - (int64_t)my, dhi = (int64_t)sg.raw_end - (int64_t)my;
     const uint32_t lo = dlo <= 0 ? 0u : (dlo >= NB ? (uint32_t)NB : (uint32_t)dlo);
@@ -278,33 +283,50 @@ __global__ __launch_bounds__(256) void zj_k0_unstuff(ZjParams P)
         }
         n = (uint32_t)NB - ndrop;
     } else {
-        uint64_t keep = 0;
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const uint32_t byte = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            const bool inr = (uint32_t)k >= lo && (uint32_t)k < hi;
-            const bool drop = (byte == 0u) && pf;
-            if (inr && !drop) keep |= 1ull << k;
-            pf = inr && (byte == 0xFFu);
-        }
+        n = 0;
 #pragma unroll
         for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) {
-            const uint32_t nib = (uint32_t)(keep >> (4 * j)) & 15u;
-            const uint32_t spread = (nib | (nib << 7) | (nib << 14) | (nib << 21)) & 0x01010101u;
-            kill[j] = (spread << 7) ^ 0x80808080u;
+            uint32_t kl = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) {
+                const uint32_t byte = (w[j] >> (8u * k)) & 0xFFu;
+                const bool inr = 4u * j + k >= lo && 4u * j + k < hi;
+                const bool kept = inr && !((byte == 0u) && pf);
+                if (!kept) kl |= 0x80u << (8u * k);
+                n += kept ? 1u : 0u;
+                pf = inr && (byte == 0xFFu);
+            }
+            kill[j] = kl;
         }
-        n = (uint32_t)__popcll(keep);
     }
     uint32_t total;
-    const uint32_t inc = block_incl_scan<4>(n, wsum, &total); // its barriers also end the reads of the raw tile
-
+    const uint32_t inc = block_incl_scan<ZJ_K0_THREADS / 64>(n, wsum, &total); // its barriers also end the reads of the raw tile
+    // the tile's own count goes out first, so that the tiles behind it can already add it up
+    if (tid == 0 && tj > 0) __hip_atomic_store(&P.tile_status[tile], ZJ_TS_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        // Compaction in LDS, from byte ZJ_K0_PAD on, before the tile's place in the segment is known (the
+        // wait for the predecessors is hidden behind it).  Every byte is stored at the position of the next
+        // kept byte: a byte that is not kept is overwritten by the kept byte that follows it in the same
+        // thread (LDS stores of a lane are executed in order); only a thread's last byte has no successor
+        // and goes to a spare slot.
+        uint32_t o = ZJ_K0_PAD + inc - n;
+#pragma unroll
+        for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) {
+                const uint32_t dead = (kill[j] >> (8u * k + 7u)) & 1u;
+                const uint32_t at = (j == ZJ_K0_WORDS - 1u && k == 3u && dead) ? ZJ_K0_TILE + ZJ_K0_PAD + 48u : o;
+                buf[at] = (uint8_t)(w[j] >> (8u * k));
+                o += 1u - dead;
+            }
+        }
+    }
     if (tid < 64u) {
         // look-back by the first wavefront: 64 predecessors per step.  The nearest tile that has published
         // an inclusive prefix ends the walk; every tile between it and this one must at least have
         // published its own count, otherwise the step is repeated.
         uint32_t excl = 0;
         if (tj > 0) {
-            if (tid == 0) __hip_atomic_store(&P.tile_status[tile], ZJ_TS_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int64_t base = (int64_t)tile - 1;
             for (;;) {
                 const int64_t j = base - (int64_t)tid;
@@ -314,7 +336,7 @@ __global__ __launch_bounds__(256) void zj_k0_unstuff(ZjParams P)
                 const uint64_t incl = __ballot(flag == 2u), pending = __ballot(flag == 0u);
                 const uint32_t first = incl ? (uint32_t)__builtin_ctzll(incl) : 64u;
                 const uint64_t needed = first >= 63u ? ~0ull : ((2ull << first) - 1ull); // lanes 0..first
-                if (pending & needed) { __builtin_amdgcn_s_sleep(1); continue; }
+                if (pending & needed) { __builtin_amdgcn_s_sleep(8); continue; }
                 uint32_t v = (tid <= first) ? (uint32_t)sv : 0u;
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
@@ -330,34 +352,34 @@ __global__ __launch_bounds__(256) void zj_k0_unstuff(ZjParams P)
         }
     }
     __syncthreads();
+    // Copy out in 16-byte pieces aligned in global memory.  In piece coordinates (byte 0 = the aligned
+    // address at or below the tile's first output byte) the tile owns [shift, shift + total); coordinate c
+    // is LDS byte ZJ_K0_PAD + c - shift, so a piece is 16 bytes at one fixed misalignment for the whole
+    // tile: two aligned 16-byte LDS reads and a byte funnel shift.
     const uint32_t prefix = s_prefix;
-    const uint32_t shift = prefix & 15u; // LDS position = global position mod 16, so pieces line up
-    {
-        // every byte is stored at the position of the next kept byte: a byte that is not kept is
-        // overwritten by the kept byte that follows it in the same thread (LDS stores of a lane are
-        // executed in order); only a thread's last byte has no successor and goes to a spare slot
-        uint32_t o = shift + inc - n;
-#pragma unroll
-        for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) {
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; k++) {
-                const uint32_t dead = (kill[j] >> (8u * k + 7u)) & 1u;
-                const uint32_t at = (j == ZJ_K0_WORDS - 1u && k == 3u && dead) ? ZJ_K0_TILE + 32u : o;
-                buf[at] = (uint8_t)(w[j] >> (8u * k));
-                o += 1u - dead;
-            }
-        }
-    }
-    __syncthreads();
+    const uint32_t shift = prefix & 15u;
     uint8_t *out = P.ust + sg.out_off + (prefix - shift);
     const uint32_t endpos = shift + total;
-    for (uint32_t pc = tid; pc * 16u < endpos; pc += 256u) {
+    const uint32_t mis = (uint32_t)__builtin_amdgcn_readfirstlane((int)((ZJ_K0_PAD - shift) & 15u)); // LDS misalignment of a piece
+    const uint32_t wo = mis >> 2, bs = mis & 3u;
+    for (uint32_t pc = tid; pc * 16u < endpos; pc += ZJ_K0_THREADS) {
         const uint32_t b0 = pc * 16u;
+        const uint32_t src = ZJ_K0_PAD + b0 - shift; // >= 1
         if (b0 >= shift && b0 + 16u <= endpos) {
-            *reinterpret_cast<uint4 *>(out + b0) = *reinterpret_cast<const uint4 *>(buf + b0);
+            const uint4 lo = *reinterpret_cast<const uint4 *>(buf + (src & ~15u));
+            const uint4 hi = *reinterpret_cast<const uint4 *>(buf + (src & ~15u) + 16u);
+            uint32_t a0, a1, a2, a3, a4;
+            switch (wo) { // uniform
+            case 0: a0 = lo.x; a1 = lo.y; a2 = lo.z; a3 = lo.w; a4 = hi.x; break;
+            case 1: a0 = lo.y; a1 = lo.z; a2 = lo.w; a3 = hi.x; a4 = hi.y; break;
+            case 2: a0 = lo.z; a1 = lo.w; a2 = hi.x; a3 = hi.y; a4 = hi.z; break;
+            default: a0 = lo.w; a1 = hi.x; a2 = hi.y; a3 = hi.z; a4 = hi.w; break;
+            }
+            *reinterpret_cast<uint4 *>(out + b0) = make_uint4(__builtin_amdgcn_alignbyte(a1, a0, bs), __builtin_amdgcn_alignbyte(a2, a1, bs),
+                                                              __builtin_amdgcn_alignbyte(a3, a2, bs), __builtin_amdgcn_alignbyte(a4, a3, bs));
         } else { // a piece shared with the neighbouring tile: only this tile's bytes
             for (uint32_t k = 0; k < 16u; k++)
-                if (b0 + k >= shift && b0 + k < endpos) out[b0 + k] = buf[b0 + k];
+                if (b0 + k >= shift && b0 + k < endpos) out[b0 + k] = buf[src + k];
         }
     }
 }
@@ -1390,7 +1412,7 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     if (ev) hipEventRecord(ev[e++], st);
     hipMemsetAsync(P.flags, 0, 16, st);
     hipMemsetAsync(P.tile_status, 0, (size_t)L.ntiles * sizeof(uint64_t) + (size_t)L.nseg * sizeof(uint32_t), st); // look-back words and the tickets behind them
-    if (L.ntiles) hipLaunchKernelGGL(zj_k0_unstuff, dim3(L.ntiles), dim3(256), 0, st, P);
+    if (L.ntiles) hipLaunchKernelGGL(zj_k0_unstuff, dim3(L.ntiles), dim3(ZJ_K0_THREADS), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1a_sync, dim3(L.nchunks / 4), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);

@@ -247,23 +247,39 @@ __global__ __launch_bounds__(ZJ_K0_THREADS) void zj_k0_unstuff(ZjParams P)
     const uint64_t my = t0 + (uint64_t)tid * (ZJ_K0_WORDS * 4u);
     const uint8_t *raw = P.raw;
 
-    // the tile into LDS in 16-byte pieces (coalesced), then every thread picks up its words
-    for (uint32_t pc = tid; pc < ZJ_K0_TILE / 16u; pc += ZJ_K0_THREADS) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (t0 + 16u * pc < sg.raw_end) v = *reinterpret_cast<const uint4 *>(raw + t0 + 16u * pc);
-        reinterpret_cast<uint4 *>(buf)[pc] = v;
-    }
-    __syncthreads();
-    uint32_t w[ZJ_K0_WORDS];
-#pragma unroll
-    for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) w[j] = reinterpret_cast<const uint32_t *>(buf)[tid * ZJ_K0_WORDS + j];
     // bytes of this thread that belong to the segment: [lo, hi) of 0..NB (signed differences, clamped)
     constexpr int NB = (int)(ZJ_K0_WORDS * 4u);
     const int64_t dlo = (int64_t)sg.raw_begin - (int64_t)my, dhi = (int64_t)sg.raw_end - (int64_t)my;
     const uint32_t lo = dlo <= 0 ? 0u : (dlo >= NB ? (uint32_t)NB : (uint32_t)dlo);
     const uint32_t hi = dhi <= 0 ? 0u : (dhi >= NB ? (uint32_t)NB : (uint32_t)dhi);
-    uint32_t pf = 0; // is the byte before this thread's first byte an FF of the segment
-    if (dlo < 0 && dhi >= 0) pf = raw[my - 1] == 0xFFu;
+    // The byte before this thread's first byte, and the tile in 16-byte pieces (coalesced) on its way into
+    // LDS, where every thread then picks up its words.  The loads are unconditional (addresses clamped
+    // into the segment, results masked afterwards) so that all of them are in flight before the first is
+    // waited for: one trip to memory per tile, not one per piece.
+    const bool has_before = dlo < 0 && dhi >= 0;
+    const uint32_t pfb = raw[has_before ? my - 1 : a0];
+    constexpr uint32_t NPC = ZJ_K0_TILE / 16u, NLD = (NPC + ZJ_K0_THREADS - 1u) / ZJ_K0_THREADS;
+    const bool nonempty = sg.raw_end > a0;
+    const uint64_t lim = nonempty ? ((sg.raw_end - 1u - a0) & ~15ull) : 0ull; // offset of the last piece with bytes of the segment
+    uint4 ld[NLD];
+#pragma unroll
+    for (uint32_t i = 0; i < NLD; i++) {
+        const uint64_t po = (uint64_t)tj * ZJ_K0_TILE + 16u * (tid + i * ZJ_K0_THREADS);
+        ld[i] = *reinterpret_cast<const uint4 *>(raw + a0 + (po < lim ? po : lim));
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < NLD; i++) {
+        const uint32_t pc = tid + i * ZJ_K0_THREADS;
+        const uint64_t po = (uint64_t)tj * ZJ_K0_TILE + 16u * pc;
+        const bool ok = nonempty && po <= lim;
+        const uint4 v = make_uint4(ok ? ld[i].x : 0u, ok ? ld[i].y : 0u, ok ? ld[i].z : 0u, ok ? ld[i].w : 0u);
+        if (pc < NPC) reinterpret_cast<uint4 *>(buf)[pc] = v;
+    }
+    uint32_t pf = has_before && pfb == 0xFFu; // is the byte before this thread's first byte an FF of the segment
+    __syncthreads();
+    uint32_t w[ZJ_K0_WORDS];
+#pragma unroll
+    for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) w[j] = reinterpret_cast<const uint32_t *>(buf)[tid * ZJ_K0_WORDS + j];
 
     // kill[j]: bit 7 of byte k set when byte 4j+k is not kept (a stuffed 00, or outside the segment)
     uint32_t kill[ZJ_K0_WORDS];

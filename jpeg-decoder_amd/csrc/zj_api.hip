@@ -201,6 +201,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
 
     const uint32_t l2_cap = (flags & ZJ_FLAG_NO_SECOND_LEVEL) ? 0u : ZJ_L2_SIZE;
     uint32_t subbits = flags & 0xFFFFFFu;
+    const bool subbits_forced = subbits != 0;
     if (subbits == 0) {
         // Enough subsequences to give every SIMD of the GPU a few wavefronts, and no more: the longer a
         // subsequence, the smaller the share of the synchronisation rounds.
@@ -336,6 +337,11 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             if (nint > offs.size()) nint = offs.size();
         }
         uint32_t sub_in_img = 0;
+        uint32_t open_lanes = 0, open_used = 0; // the packed chunk under construction: its group size, lanes taken
+        // Bits per lane wanted in the groups of short segments.  A lone wavefront needs about 20 us per
+        // window whatever the group size, and the walk into the neighbours costs about nine windows more, so
+        // groups of few long subsequences finish as early as many short ones and do a fraction of the work.
+        const uint32_t small_target = subbits_forced ? subbits : std::max(subbits, 16384u);
         for (uint64_t k = 0; k < nseg; k++) {
             ZjSegDev s;
             memset(&s, 0, sizeof s);
@@ -352,20 +358,37 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             s.out_cap = (uint32_t)(align_up(rl, 16) + 96);
             ust_total += s.out_cap;
             s.img = (uint32_t)i;
-            zj_seg_layout((uint64_t)rl * 8u, subbits, &s.subbits, &s.nsub);
+            zj_seg_layout((uint64_t)rl * 8u, subbits, small_target, &s.subbits, &s.nsub, &s.lanes);
             s.nc = s.subbits / ZJ_WIN_BITS;
-            s.first_sub = d.first_sub + sub_in_img;
-            const uint32_t nchunk = (s.nsub + 63) / 64;
             s.first_win = (uint32_t)nwin_total;
-            nwin_total += (uint64_t)nchunk * 64u * s.nc;
+            if (s.lanes == 64u) {
+                // whole chunks of its own
+                sub_in_img = (uint32_t)align_up(sub_in_img, 64);
+                open_lanes = 0;
+                s.first_sub = d.first_sub + sub_in_img;
+                const uint32_t nchunk = (s.nsub + 63) / 64;
+                nwin_total += (uint64_t)nchunk * 64u * s.nc;
+                for (uint32_t c = 0; c < nchunk; c++) chunk_seg.push_back((uint32_t)b->segs.size());
+                sub_in_img += nchunk * 64;
+            } else {
+                // a group of lanes in a packed chunk, which holds groups of one size only
+                if (open_lanes != s.lanes || open_used + s.lanes > 64u) {
+                    sub_in_img = (uint32_t)align_up(sub_in_img, 64);
+                    chunk_seg.push_back((uint32_t)b->segs.size());
+                    open_lanes = s.lanes;
+                    open_used = 0;
+                }
+                s.first_sub = d.first_sub + sub_in_img;
+                nwin_total += (uint64_t)s.lanes * s.nc;
+                sub_in_img += s.lanes;
+                open_used += s.lanes;
+            }
             s.first_tile = (uint32_t)tile_seg.size();
             s.ntiles = (uint32_t)((s.raw_end - (s.raw_begin & ~15ull) + ZJ_UNSTUFF_TILE - 1u) / ZJ_UNSTUFF_TILE);
             if (s.ntiles == 0) s.ntiles = 1; // an empty segment still publishes its payload length
             for (uint32_t t = 0; t < s.ntiles; t++) tile_seg.push_back((uint32_t)b->segs.size());
             s.first_ptile = (uint32_t)ptile_seg.size();
             for (uint64_t w = 0; w < (uint64_t)s.nsub * s.nc; w += 256u) ptile_seg.push_back((uint32_t)b->segs.size());
-            for (uint32_t c = 0; c < nchunk; c++) chunk_seg.push_back((uint32_t)b->segs.size());
-            sub_in_img += nchunk * 64;
             const uint64_t m0 = ri ? k * ri : 0;
             const uint64_t mc = ri ? std::min<uint64_t>(ri, nmcu - m0) : nmcu;
             s.first_block = d.first_block + (uint32_t)(m0 * d.bpm);
@@ -375,6 +398,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             for (uint32_t t = 0; t < s.ndtiles; t++) dtile_seg.push_back((uint32_t)b->segs.size());
             b->segs.push_back(s);
         }
+        sub_in_img = (uint32_t)align_up(sub_in_img, 64);
         d.nsub = (uint32_t)align_up(sub_in_img, 256);
         for (uint32_t c = sub_in_img / 64; c < d.nsub / 64; c++) chunk_seg.push_back(ZJ_NONE);
         nsub_total += d.nsub;
@@ -446,6 +470,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.rgb = b->d_rgb;
     P.rgb_stride = b->d_stride;
     P.nchunks = (uint32_t)chunk_seg.size();
+    P.nseg = (uint32_t)b->segs.size();
     ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.wluts && P.canons && P.qts && raw && P.ust &&
          P.seg_payload_bits && P.seg_found && P.winfo && P.wbase && P.bitmap && P.ptile_seg && P.tile_seg && P.tile_status && P.dtile_seg && P.dtile_sum && P.blockpos && P.dcabs && P.dcbits && P.qcoef && P.status &&
          P.flags && b->d_rgb && b->d_stride;

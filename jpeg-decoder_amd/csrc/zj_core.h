@@ -76,13 +76,14 @@ struct ZjSegDev {
     uint64_t out_off;            // byte offset of the unstuffed stream in its arena (multiple of 16)
     uint32_t out_cap;            // bytes reserved there (multiple of 16, >= payload + 16, zero filled)
     uint32_t img;
-    uint32_t first_sub;          // global subsequence index of the segment's first lane (multiple of 64)
+    uint32_t first_sub;          // global subsequence index of the segment's first lane (multiple of `lanes`)
     uint32_t nsub;               // subsequences that can hold payload: ceil(raw bits / subsequence bits)
     uint32_t first_block;        // global block index of the segment's first block
     uint32_t nblocks;            // blocks coded in this segment
     uint32_t subbits;            // bits per subsequence of this segment (multiple of ZJ_WIN_BITS)
     uint32_t nc;                 // windows per subsequence = subbits / ZJ_WIN_BITS
-    uint32_t first_win;          // offset of the segment's window records / window bases (64 * nc per chunk)
+    uint32_t lanes;              // lanes of a wavefront the segment's subsequences share: 64, or 1..32 in a packed chunk
+    uint32_t first_win;          // offset of the segment's window records / window bases (lanes * nc per chunk or group)
     uint32_t first_ptile;        // first workgroup of the position pass (256 windows each)
     uint32_t first_tile, ntiles; // tiles of the unstuff pass (15 KiB of raw bytes each, from raw_begin & ~15)
     uint32_t first_dtile, ndtiles; // tiles of the DC scan (256 MCUs each, at least one)
@@ -108,19 +109,35 @@ struct ZjSegDev {
 #define ZJ_INFO_STATE_MASK 0xFFFFu
 
 // Index of the record of window c of subsequence q (both relative to the segment) inside the
-// segment's record area; nc = windows per subsequence.
-ZJ_HD uint32_t zj_rec_index(uint32_t q, uint32_t c, uint32_t nc) { return ((q >> 6) * nc + c) * 64u + (q & 63u); }
+// segment's record area; nc = windows per subsequence, lanes = lanes of a wavefront the segment's
+// subsequences share (64, or the size of the segment's group in a packed chunk).
+ZJ_HD uint32_t zj_rec_index(uint32_t q, uint32_t c, uint32_t nc, uint32_t lanes = 64u) { return ((q / lanes) * nc + c) * lanes + (q % lanes); }
 
-// Subsequence size of a segment of `raw_bits` stuffed bits for a wanted size of `target` bits: the
-// segment is cut into a whole number of chunks (64 subsequences each) and the subsequence size is
-// what fills them evenly, rounded up to whole windows.  Every lane of every chunk then has work.
-ZJ_HD void zj_seg_layout(uint64_t raw_bits, uint32_t target, uint32_t *subbits, uint32_t *nsub)
+// How a segment of `raw_bits` stuffed bits is cut into subsequences for a wanted size of `target` bits.
+// A segment that fills at least half a chunk (64 subsequences) at that size is cut into a whole number
+// of chunks, with the subsequence size that fills them evenly, rounded up to whole windows: every lane
+// of every chunk then has work (*lanes = 64).  A shorter segment shares a chunk with its neighbours: it
+// gets a group of *lanes = 1, 2, 4 .. 32 lanes, as many as it has subsequences of about `small_target`
+// bits, so that a wavefront is filled by several segments instead of by slivers of one (a subsequence
+// much shorter than the distance a wrong guess survives is mostly walked again by its neighbours).
+ZJ_HD void zj_seg_layout(uint64_t raw_bits, uint32_t target, uint32_t small_target, uint32_t *subbits, uint32_t *nsub, uint32_t *lanes)
 {
     if (target < ZJ_WIN_BITS) target = ZJ_WIN_BITS;
-    uint64_t nchunk = (raw_bits + 32ull * target) / (64ull * target); // nearest whole number of chunks
-    if (nchunk == 0) nchunk = 1;
-    uint64_t sb = (raw_bits + 64ull * nchunk - 1) / (64ull * nchunk);
-    sb = (sb + ZJ_WIN_BITS - 1) / ZJ_WIN_BITS * ZJ_WIN_BITS;
+    if (small_target < target) small_target = target;
+    uint64_t per_lane;
+    if (raw_bits >= 32ull * target) {
+        const uint64_t nchunk = (raw_bits + 32ull * target) / (64ull * target); // nearest whole number of chunks, at least one
+        per_lane = (raw_bits + 64ull * nchunk - 1) / (64ull * nchunk);
+        *lanes = 64u;
+    } else {
+        uint64_t want = (raw_bits + small_target / 2u) / small_target;
+        if (want > 32u) want = 32u;
+        uint32_t g = 1;
+        while (g < want) g *= 2u;
+        per_lane = (raw_bits + g - 1u) / g;
+        *lanes = g;
+    }
+    uint64_t sb = (per_lane + ZJ_WIN_BITS - 1) / ZJ_WIN_BITS * ZJ_WIN_BITS;
     if (sb == 0) sb = ZJ_WIN_BITS;
     *subbits = (uint32_t)sb;
     *nsub = (uint32_t)((raw_bits + sb - 1) / sb);

@@ -52,6 +52,7 @@ struct ZjParams {
     uint8_t *const *rgb;        // [image] device pointers
     const size_t *rgb_stride;   // [image]
     uint32_t nchunks;
+    uint32_t nseg;
 };
 
 #define ZJ_K2_NS 4 // strips per workgroup of the IDCT/colour kernel

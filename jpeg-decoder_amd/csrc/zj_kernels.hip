@@ -471,6 +471,73 @@ __device__ __forceinline__ void zj_k1a_body(const ZjParams &P, const ZjImgDev &i
     }
 }
 
+// A packed chunk: short segments share the wavefront, each with a group of G = 1, 2, 4 .. 32 lanes (the
+// same G for the whole chunk).  The lanes of a group do among themselves what the 64 lanes of an ordinary
+// chunk do; G = 1 is the plain sequential walk of a restart interval from its known start.  Everything
+// that is per segment -- stream, bitmap, record area, sizes -- is per lane here.
+template <bool CANON>
+__device__ __forceinline__ void zj_k1a_body_packed(const ZjParams &P, const ZjImgDev &im, const uint16_t *lut, uint32_t *col, uint32_t chunk,
+                                                   uint32_t seg0, uint32_t G, uint32_t lane)
+{
+    const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
+    ZjSel sel = {im.bpm, im.dcsel, im.acsel};
+    const uint32_t selw = zj_selword(sel);
+
+    const uint32_t grp = lane / G, jl = lane % G;
+    const uint32_t sidx = seg0 + grp;
+    bool have = sidx < P.nseg;
+    uint32_t NC = 1, SB = ZJ_WIN_BITS, nsub = 0, pay = 0;
+    const uint32_t *stream = nullptr;
+    uint32_t *bitmap = nullptr, *rec = nullptr;
+    if (have) {
+        const ZjSegDev &sg = P.segs[sidx];
+        have = sg.lanes == G && sg.first_sub == chunk * 64u + grp * G; // the group exists in this chunk
+        if (have) {
+            NC = sg.nc; SB = sg.subbits; nsub = sg.nsub;
+            pay = P.seg_payload_bits[sidx];
+            stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
+            bitmap = reinterpret_cast<uint32_t *>(P.bitmap + sg.out_off);
+            rec = P.winfo + sg.first_win; // [window c][lane of the group]
+        }
+    }
+    auto active = [&](uint32_t q) { return have && q < nsub && (uint64_t)q * SB < (uint64_t)pay; };
+    auto sub_stop = [&](uint32_t q) { const uint64_t e = (uint64_t)(q + 1u) * SB; return e < pay ? (uint32_t)e : pay; };
+    ZjBitsLds bits;
+    bool primed = false;
+    ZjState st = {jl * SB, 0, 0};
+    const bool act0 = active(jl);
+    {
+        const uint32_t end = act0 ? sub_stop(jl) : 0u;
+        for (uint32_t c = 0;; c++) {
+            const bool run = act0 && c < NC && st.p < end;
+            if (!__any(run)) break;
+            const uint32_t w = jl * NC + c;
+            const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
+            if (run) rec[c * G + jl] = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
+        }
+    }
+    bool done = !act0;
+    for (uint32_t k = 1; k < G; k++) {
+        const uint32_t tgt = jl + k;
+        bool act = !done && tgt < G && active(tgt);
+        if (!act) done = true;
+        if (!__any(act)) break;
+        const uint32_t end = act ? sub_stop(tgt) : 0u;
+        for (uint32_t c = 0;; c++) {
+            const bool run = act && c < NC && st.p < end;
+            if (!__any(run)) break;
+            const uint32_t w = tgt * NC + c;
+            const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
+            if (run) {
+                const uint32_t nw = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
+                const uint32_t old = zj_load_coherent(&rec[c * G + tgt]);
+                rec[c * G + tgt] = nw;
+                if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0u) { act = false; done = true; }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
 {
     __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
@@ -482,8 +549,16 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
     const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
     load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
     __syncthreads();
-    if (im.flags & 2u) zj_k1a_body<true>(P, im, lut, col, chunk, lane);
-    else zj_k1a_body<false>(P, im, lut, col, chunk, lane);
+    const uint32_t seg = P.chunk_seg[chunk];
+    if (seg == ZJ_NONE) return; // wave-uniform: a padding chunk
+    const uint32_t G = P.segs[seg].lanes;
+    if (G == 64u) {
+        if (im.flags & 2u) zj_k1a_body<true>(P, im, lut, col, chunk, lane);
+        else zj_k1a_body<false>(P, im, lut, col, chunk, lane);
+    } else {
+        if (im.flags & 2u) zj_k1a_body_packed<true>(P, im, lut, col, chunk, seg, G, lane);
+        else zj_k1a_body_packed<false>(P, im, lut, col, chunk, seg, G, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------- k1b: fix
@@ -513,7 +588,7 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
     const uint32_t seg = P.chunk_seg[chunk];
     if (seg == ZJ_NONE) return;
     const ZjSegDev sg = P.segs[seg];
-    if (chunk * 64u == sg.first_sub) return; // the first chunk of a segment starts from the true state
+    if (sg.lanes != 64u || chunk * 64u == sg.first_sub) return; // packed chunks hold whole segments; a segment's first chunk starts from the true state
     const uint32_t SB = sg.subbits, NC = sg.nc;
     const uint32_t pay = P.seg_payload_bits[seg];
     const uint32_t q0 = chunk * 64u - sg.first_sub;
@@ -577,7 +652,7 @@ __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
         uint32_t n = 0;
         if (wi < nwin) {
             const uint32_t q = wi / NC, c = wi - q * NC;
-            n = rec[zj_rec_index(q, c, NC)] >> 16;
+            n = rec[zj_rec_index(q, c, NC, sg.lanes)] >> 16;
         }
         uint32_t total;
         uint32_t inc = block_incl_scan<4>(n, wsum, &total);

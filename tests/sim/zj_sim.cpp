@@ -63,12 +63,12 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
         ust.resize(ust.size() + 1024, 0);
         while (ust.size() % 4) ust.push_back(0);
         const uint32_t *stream = (const uint32_t *)ust.data();
-        uint32_t SB, nsub;
-        zj_seg_layout((uint64_t)(end - beg) * 8u, subbits, &SB, &nsub);
-        const uint32_t nchunk = (nsub + 63) / 64;
+        uint32_t SB, nsub, LN; // LN: lanes the segment's subsequences share (a whole wavefront, or a group of a packed chunk)
+        zj_seg_layout((uint64_t)(end - beg) * 8u, subbits, subbits, &SB, &nsub, &LN);
+        const uint32_t nchunk = (nsub + LN - 1) / LN;
         const uint32_t NC = SB / ZJ_WIN_BITS;
         const uint32_t selw = zj_selword(sel);
-        std::vector<uint32_t> rec((size_t)nchunk * 64 * NC + 1, 0), wbase((size_t)nchunk * 64 * NC + 1, 0);
+        std::vector<uint32_t> rec((size_t)nchunk * LN * NC + 1, 0), wbase((size_t)nchunk * LN * NC + 1, 0);
         std::vector<uint32_t> bitmap(ust.size() / 4 + 64, 0);
         auto active = [&](uint32_t q) { return q < nsub && (uint64_t)q * SB < pay; };
         auto send = [&](uint32_t q) { uint64_t e = (uint64_t)(q + 1) * SB; return e < pay ? (uint32_t)e : pay; };
@@ -82,35 +82,35 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
         for (uint32_t ch = 0; ch < nchunk; ch++) {
             ZjState st[64];
             bool done[64];
-            for (uint32_t l = 0; l < 64; l++) {
-                uint32_t jl = ch * 64 + l;
+            for (uint32_t l = 0; l < LN; l++) {
+                uint32_t jl = ch * LN + l;
                 done[l] = !active(jl);
                 st[l] = {jl * SB, 0, 0};
                 if (done[l]) continue;
                 for (uint32_t c = 0; c < NC; c++) {
                     if (st[l].p >= send(jl)) break;
-                    rec[zj_rec_index(jl, c, NC)] = window(st[l], jl * NC + c, send(jl));
+                    rec[zj_rec_index(jl, c, NC, LN)] = window(st[l], jl * NC + c, send(jl));
                 }
             }
             uint32_t rounds = 0;
-            for (uint32_t k2 = 1; k2 < 64; k2++) {
+            for (uint32_t k2 = 1; k2 < LN; k2++) {
                 bool any = false;
                 bool act[64];
-                for (uint32_t l = 0; l < 64; l++) {
-                    act[l] = !done[l] && l + k2 < 64 && active(ch * 64 + l + k2);
+                for (uint32_t l = 0; l < LN; l++) {
+                    act[l] = !done[l] && l + k2 < LN && active(ch * LN + l + k2);
                     if (!act[l]) done[l] = true;
                     any = any || act[l];
                 }
                 if (!any) break;
                 rounds++;
                 // the walks of one round touch distinct subsequences, so lane order is free
-                for (uint32_t l = 0; l < 64; l++) {
+                for (uint32_t l = 0; l < LN; l++) {
                     if (!act[l]) continue;
-                    uint32_t q = ch * 64 + l + k2;
+                    uint32_t q = ch * LN + l + k2;
                     for (uint32_t c = 0; c < NC; c++) {
                         if (st[l].p >= send(q)) break;
                         uint32_t nw = window(st[l], q * NC + c, send(q));
-                        uint32_t &r = rec[zj_rec_index(q, c, NC)];
+                        uint32_t &r = rec[zj_rec_index(q, c, NC, LN)];
                         uint32_t old = r;
                         r = nw;
                         if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0) { done[l] = true; break; }
@@ -123,19 +123,19 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
         }
         // k1b: one pass of boundary fix-up (lane order = any; emulate ascending)
         for (uint32_t ch = 1; ch < nchunk; ch++) {
-            uint32_t q0 = ch * 64;
+            uint32_t q0 = ch * LN;
             if (!active(q0)) continue;
-            ZjState st = zj_unpack_state(rec[zj_rec_index(q0 - 1, NC - 1, NC)], q0 * SB);
+            ZjState st = zj_unpack_state(rec[zj_rec_index(q0 - 1, NC - 1, NC, LN)], q0 * SB);
             uint32_t steps = 0;
             bool synced = false;
-            for (uint32_t t = 0; t < 64 && !synced; t++) {
+            for (uint32_t t = 0; t < LN && !synced; t++) {
                 uint32_t q = q0 + t;
                 if (!active(q)) { synced = true; break; }
                 for (uint32_t c = 0; c < NC; c++) {
                     if (st.p >= send(q)) break;
                     steps++;
                     uint32_t nw = window(st, q * NC + c, send(q));
-                    uint32_t &r = rec[zj_rec_index(q, c, NC)];
+                    uint32_t &r = rec[zj_rec_index(q, c, NC, LN)];
                     uint32_t old = r;
                     r = nw;
                     if (((old ^ nw) & ZJ_INFO_STATE_MASK) == 0) { synced = true; break; }
@@ -150,7 +150,7 @@ extern "C" int zjsim_decode(const zj_image *im, uint32_t subbits, int16_t *qcoef
         uint32_t carry = 0;
         for (uint32_t wi = 0; wi < nwin; wi++) {
             wbase[wi] = carry;
-            carry += rec[zj_rec_index(wi / NC, wi % NC, NC)] >> 16;
+            carry += rec[zj_rec_index(wi / NC, wi % NC, NC, LN)] >> 16;
         }
         const uint32_t found = std::min(carry, nblocks);
         // k1p: bitmap -> block positions
@@ -223,4 +223,10 @@ extern "C" int zjsim_lookup_check(const zj_huff *h, uint32_t l2_cap, uint32_t nt
         }
     }
     return bad;
+}
+
+// The planner's cut of a segment into subsequences (zj_core.h), for the layout test.
+extern "C" void zjsim_seg_layout(uint64_t raw_bits, uint32_t target, uint32_t small_target, uint32_t *subbits, uint32_t *nsub, uint32_t *lanes)
+{
+    zj_seg_layout(raw_bits, target, small_target, subbits, nsub, lanes);
 }

@@ -150,6 +150,22 @@ def test_long_blocks_and_many_segments(ctx):
             assert_same(data, rgb[0], st[0], coef[0])
 
 
+def test_short_segments_share_wavefronts(ctx):
+    """Restart intervals far shorter than a wavefront's worth of subsequences are packed several to a
+    wavefront, in lane groups of 1 to 32; forced subsequence sizes make the group size change from segment to
+    segment inside one image, and a batch mixes such images with ordinary ones."""
+    files = [synth.encode(640, 480, 2, 2, 90, 0, 51, 5), synth.encode(320, 240, 1, 1, 95, 2, 52, 3), synth.encode(512, 512, 2, 1, 75, 1, 53, 16),
+             synth.encode(256, 256, 2, 2, 90, 0, 54, 0), synth.encode(1024, 64, 0, 0, 90, 2, 55, 7), synth.encode(640, 480, 2, 2, 98, 2, 56, 40)]
+    imgs = [J.ParsedImage(f) for f in files]
+    refs = [oracle.decode(f) for f in files]
+    for sb in (0, 512, 1024, 2048, 4096, 16384):
+        rgb, st, coef = J.decode_images(ctx, imgs, subseq_bits=sb, want_coef=True)
+        assert not st.any(), (sb, st)
+        for i, r in enumerate(refs):
+            assert np.array_equal(coef[i], r.qcoef), (sb, i)
+            assert np.array_equal(rgb[i], r.rgb), (sb, i)
+
+
 def test_batch_of_1080p_is_deterministic_and_uniform(ctx):
     """Size-independent property at benchmark scale: 64 copies of 4 distinct 1080p images decode to
     identical coefficients and pixels per source image, run after run (no order-dependent results)."""

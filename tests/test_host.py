@@ -117,6 +117,30 @@ def test_stage1_walk_synthetic(params):
         assert np.array_equal(q, want)
 
 
+def test_segment_layout_properties():
+    """Every segment is covered by its subsequences; long segments fill whole 64-lane chunks evenly, short ones
+    get a power-of-two group of lanes that holds all their subsequences."""
+    S = sim()
+    S.zjsim_seg_layout.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32] + [C.POINTER(C.c_uint32)] * 3
+    S.zjsim_seg_layout.restype = None
+    rng = np.random.default_rng(3)
+    sb, ns, ln = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    cases = [(0, 1024, 1024), (1, 512, 512), (511, 512, 512), (512, 512, 512), (32 * 1024 - 1, 1024, 16384), (32 * 1024, 1024, 16384)]
+    for _ in range(3000):
+        target = int(rng.choice([512, 1024, 2048, 4096, 65536, 20000]))
+        cases.append((int(rng.integers(0, 1 << int(rng.integers(4, 31)))), target, max(target, int(rng.choice([512, 4096, 16384])))))
+    for bits, target, small in cases:
+        S.zjsim_seg_layout(bits, target, small, C.byref(sb), C.byref(ns), C.byref(ln))
+        assert sb.value % 512 == 0 and sb.value >= 512
+        assert ns.value * sb.value >= bits and (ns.value == 0 or (ns.value - 1) * sb.value < bits)
+        if bits >= 32 * max(target, 512):
+            assert ln.value == 64
+            chunks = (ns.value + 63) // 64
+            assert chunks * 64 - ns.value < 64 and sb.value < 2 * max(target, 512) + 512
+        else:
+            assert ln.value in (1, 2, 4, 8, 16, 32) and ns.value <= ln.value
+
+
 def test_stage1_walk_reports_corruption():
     data = bytearray(synth.encode(96, 96, 2, 2, seed=3))
     i = oracle.probe(bytes(data))

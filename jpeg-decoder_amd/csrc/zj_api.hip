@@ -375,6 +375,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
                 if (open_lanes != s.lanes || open_used + s.lanes > 64u) {
                     sub_in_img = (uint32_t)align_up(sub_in_img, 64);
                     chunk_seg.push_back((uint32_t)b->segs.size());
+                    b->L.npacked++;
                     open_lanes = s.lanes;
                     open_used = 0;
                 }

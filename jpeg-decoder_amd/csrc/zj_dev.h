@@ -61,6 +61,7 @@ struct ZjParams {
 
 struct ZjLaunch {
     uint32_t nseg, nchunks, nblk256, nstrips, nk1w, nptiles, ntiles, ndtiles;
+    uint32_t npacked; // chunks shared by several short segments (the packed form of the sync kernel)
     uint32_t k2_first[ZJ_K2_CLASSES], k2_count[ZJ_K2_CLASSES]; // stage-2 workgroups per layout (2x2, 1x1, 2x1, 1x2, one component)
     int fix_iters;
 };

@@ -550,15 +550,36 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
     load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
     __syncthreads();
     const uint32_t seg = P.chunk_seg[chunk];
-    if (seg == ZJ_NONE) return; // wave-uniform: a padding chunk
-    const uint32_t G = P.segs[seg].lanes;
-    if (G == 64u) {
-        if (im.flags & 2u) zj_k1a_body<true>(P, im, lut, col, chunk, lane);
-        else zj_k1a_body<false>(P, im, lut, col, chunk, lane);
-    } else {
-        if (im.flags & 2u) zj_k1a_body_packed<true>(P, im, lut, col, chunk, seg, G, lane);
-        else zj_k1a_body_packed<false>(P, im, lut, col, chunk, seg, G, lane);
+    if (seg == ZJ_NONE || P.segs[seg].lanes != 64u) return; // wave-uniform: a padding chunk, or one for the packed kernel
+    if (im.flags & 2u) zj_k1a_body<true>(P, im, lut, col, chunk, lane);
+    else zj_k1a_body<false>(P, im, lut, col, chunk, lane);
+}
+
+// The same for packed chunks; a kernel of its own so that each form keeps its own register budget
+// (launched only when the batch has packed chunks).
+__global__ __launch_bounds__(256) void zj_k1a_sync_packed(ZjParams P)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
+    __shared__ uint32_t win[4][ZJ_WIN_SLOTS * 64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t *col = &win[wave][lane];
+    const uint32_t chunk = blockIdx.x * 4u + wave;
+    bool any = false; // does this workgroup hold a packed chunk at all
+    for (uint32_t c = 0; c < 4u; c++) {
+        const uint32_t sc = P.chunk_seg[blockIdx.x * 4u + c];
+        any = any || (sc != ZJ_NONE && P.segs[sc].lanes != 64u);
     }
+    if (!any) return;
+    const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
+    const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
+    load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
+    __syncthreads();
+    const uint32_t seg = P.chunk_seg[chunk];
+    if (seg == ZJ_NONE) return;
+    const uint32_t G = P.segs[seg].lanes;
+    if (G == 64u) return;
+    if (im.flags & 2u) zj_k1a_body_packed<true>(P, im, lut, col, chunk, seg, G, lane);
+    else zj_k1a_body_packed<false>(P, im, lut, col, chunk, seg, G, lane);
 }
 
 // ---------------------------------------------------------------------------------- k1b: fix
@@ -1506,6 +1527,7 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     if (L.ntiles) hipLaunchKernelGGL(zj_k0_unstuff, dim3(L.ntiles), dim3(ZJ_K0_THREADS), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1a_sync, dim3(L.nchunks / 4), dim3(256), 0, st, P);
+    if (L.npacked) hipLaunchKernelGGL(zj_k1a_sync_packed, dim3(L.nchunks / 4), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
     for (int i = 0; i < L.fix_iters; i++) hipLaunchKernelGGL(zj_k1b_fix, dim3(L.nchunks / 4), dim3(64), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);

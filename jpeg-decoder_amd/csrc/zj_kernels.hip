@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
     uint32_t *col = &win[wave][lane];
     const uint32_t chunk = blockIdx.x * 4u + wave;
     const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
-    const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
+    const ZjImgDev im = P.imgs[P.segs[seg_first].img]; // by value: a reference would be read again after every store
     load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
     __syncthreads();
     const uint32_t seg = P.chunk_seg[chunk];
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void zj_k1a_sync_packed(ZjParams P)
     }
     if (!any) return;
     const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
-    const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
+    const ZjImgDev im = P.imgs[P.segs[seg_first].img]; // by value: a reference would be read again after every store
     load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
     __syncthreads();
     const uint32_t seg = P.chunk_seg[chunk];
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
     __shared__ uint32_t bmp[ZJ_WIN_WORDS * 64];
     const uint32_t lane = threadIdx.x;
     const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
-    const ZjImgDev &im = P.imgs[P.segs[seg_first].img];
+    const ZjImgDev im = P.imgs[P.segs[seg_first].img]; // by value: a reference would be read again after every store
     load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
     __syncthreads();
     if (lane >= 4u) return;
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256) void zj_k1p_positions(ZjParams P)
 __global__ __launch_bounds__(256) void zj_k1c_dcdiff(ZjParams P)
 {
     const uint32_t ii = P.blk256_img[blockIdx.x];
-    const ZjImgDev &im = P.imgs[ii];
+    const ZjImgDev im = P.imgs[ii]; // by value: a reference would be read again after every store
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const uint32_t gl = g - im.first_block;
     if (gl >= im.nblocks) return;
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void zj_k1d_tilesum(ZjParams P)
     const uint32_t s = P.dtile_seg[tile];
     const ZjSegDev sg = P.segs[s];
     if (sg.ndtiles == 1u) return; // nothing before its only tile
-    const ZjImgDev &im = P.imgs[sg.img];
+    const ZjImgDev im = P.imgs[sg.img]; // by value: a reference would be read again after every store
     const uint32_t nmcu = sg.nblocks / im.bpm;
     const uint32_t m = (tile - sg.first_dtile) * 256u + threadIdx.x;
     const ZjDcTile t = zj_dc_tile_load(P.dcabs + sg.first_block, m, nmcu, im.bpm, im.compsel);
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan(ZjParams P)
     const uint32_t tile = blockIdx.x;
     const uint32_t s = P.dtile_seg[tile];
     const ZjSegDev sg = P.segs[s];
-    const ZjImgDev &im = P.imgs[sg.img];
+    const ZjImgDev im = P.imgs[sg.img]; // by value: a reference would be read again after every store
     const uint32_t bpm = im.bpm, compsel = im.compsel;
     const uint32_t nmcu = sg.nblocks / bpm;
     int16_t *da = P.dcabs + sg.first_block; // holds the differences on entry
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
     __shared__ uint32_t scol[4][ZJ_K1W_SLOTS * 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t ii = P.k1w_img[blockIdx.x];
-    const ZjImgDev &im = P.imgs[ii];
+    const ZjImgDev im = P.imgs[ii]; // by value: a reference would be read again after every store
     {
         const uint4 *s4 = reinterpret_cast<const uint4 *>(P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES + 2u * ZJ_TBL_ENTRIES);
         uint4 *d4 = reinterpret_cast<uint4 *>(lut);
@@ -885,30 +885,32 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
     // Both are fetched ahead of the round that uses them -- the description two rounds ahead, the bits
     // one round ahead (their address comes out of the description) -- so that a round starts decoding
     // at once instead of waiting for two dependent trips to memory.
+    // The loads of a description are unconditional (indices clamped to an existing block) and what they
+    // return is only looked at through have / has_next in the round that uses it: a load under a
+    // condition, or a value converted on the spot, would make the wavefront wait for memory right here.
     struct Desc {
         uint32_t p0, pnext, pay, kb, dcbits;
+        uint32_t dc; // the DC value's 16 bits
         const uint32_t *stream;
-        int16_t dc;
-        bool valid, have; // the block exists / its position is known
+        bool valid, have, has_next; // the block exists / its position is known / so is the next block's
     };
     auto describe = [&](uint32_t r) -> Desc {
         Desc d;
-        d.valid = false; d.have = false; d.p0 = 0; d.pnext = 0xFFFFFFFFu; d.pay = 0; d.kb = 0; d.stream = nullptr; d.dc = 0;
-        d.dcbits = ZJ_DC_BAD;
-        if (r >= rounds) return d;
+        d.valid = false; d.have = false; d.has_next = false; d.p0 = 0; d.pnext = 0; d.pay = 0; d.kb = 0; d.stream = nullptr; d.dc = 0;
+        d.dcbits = 0;
+        if (r >= rounds) return d; // uniform
         const bool luma = r < rounds_l;
         const uint32_t sh = luma ? shl : 1u;
         const uint32_t qi = (luma ? r : r - rounds_l) * 64u + lane;
         const uint32_t mcu = m0 + (qi >> sh);
         d.kb = (luma ? 0u : nl) + (qi & ((1u << sh) - 1u));
-        if (mcu >= nmcu) return d;
-        d.valid = true;
-        const uint32_t gl = mcu * bpm + d.kb; // block index inside the image
+        d.valid = mcu < nmcu;
+        const uint32_t gl = d.valid ? mcu * bpm + d.kb : 0u; // block index inside the image
         const uint32_t g = im.first_block + gl;
         uint32_t gs = gl, fnd = found;
         d.pay = pay;
         d.stream = stream;
-        if (!oneseg) {
+        if (!oneseg) { // uniform
             const uint32_t segi = gl / im.ri_blocks;
             const uint32_t sgi = im.first_seg + segi;
             gs = gl - segi * im.ri_blocks;
@@ -916,21 +918,20 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
             d.pay = P.seg_payload_bits[sgi];
             d.stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[sgi].out_off);
         }
-        if (gs < fnd) {
-            d.have = true;
-            d.p0 = P.blockpos[g];
-            d.dc = P.dcabs[g];
-            d.dcbits = P.dcbits[g];
-            if (gs + 1u < fnd) d.pnext = P.blockpos[g + 1u];
-        }
+        d.have = d.valid && gs < fnd;
+        d.has_next = d.have && gs + 1u < fnd;
+        const uint32_t gi = d.have ? g : im.first_block;
+        d.p0 = P.blockpos[gi];
+        d.dc = (uint16_t)P.dcabs[gi];
+        d.dcbits = P.dcbits[gi];
+        d.pnext = P.blockpos[d.has_next ? g + 1u : gi];
         return d;
     };
     ZjU4 h0 = {0, 0, 0, 0}, h1 = h0, h2 = h0, h3 = h0; // bits of the current round's block
     auto fetch_head = [&](const Desc &d, ZjU4 &c0, ZjU4 &c1, ZjU4 &c2, ZjU4 &c3) {
-        if (d.have) {
-            const ZjU4 *src = reinterpret_cast<const ZjU4 *>(d.stream) + (d.p0 >> 7);
-            c0 = src[0]; c1 = src[1]; c2 = src[2]; c3 = src[3];
-        }
+        // unconditional as well: a lane without a block reads the head of the arena and ignores it
+        const ZjU4 *src = d.have ? reinterpret_cast<const ZjU4 *>(d.stream) + (d.p0 >> 7) : reinterpret_cast<const ZjU4 *>(P.ust);
+        c0 = src[0]; c1 = src[1]; c2 = src[2]; c3 = src[3];
     };
     auto stage = [&](const ZjU4 &c0, const ZjU4 &c1, const ZjU4 &c2, const ZjU4 &c3) {
 #define ZJ_SW(x) __builtin_bswap32(x)
@@ -940,27 +941,31 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
         col[12 * 64] = ZJ_SW(c3.x); col[13 * 64] = ZJ_SW(c3.y); col[14 * 64] = ZJ_SW(c3.z); col[15 * 64] = ZJ_SW(c3.w);
 #undef ZJ_SW
     };
+    // Order of memory operations in a round: the description of the round after next is requested at the
+    // top; the bits of the next round's block (requested a round ago) are staged into the column at the
+    // bottom, after this round's block is done with it and before the coefficient stores are issued, and
+    // the request for the bits after those follows at once.  Nothing ever waits for an operation that
+    // has not had a whole round to complete -- in particular not for the stores.
     Desc cur = describe(0);
     fetch_head(cur, h0, h1, h2, h3);
     Desc nxt = describe(1);
+    stage(h0, h1, h2, h3);
+    fetch_head(nxt, h0, h1, h2, h3);
     for (uint32_t r = 0; r < rounds; r++) {
 #pragma unroll
         for (int i = 0; i < 33; i++) row32[i] = 0;
         const bool luma = r < rounds_l;
         const uint32_t sh = luma ? shl : 1u;
         const uint32_t qbase = (luma ? r : r - rounds_l) * 64u;
-        ZjU4 n0 = {0, 0, 0, 0}, n1 = n0, n2 = n0, n3 = n0;
-        fetch_head(nxt, n0, n1, n2, n3);
         const Desc nn = describe(r + 2u);
 
         // ---- this round's block (src/decoder.rs:186-235; the DC value comes from the prefix scan)
-        uint32_t p = cur.p0 + cur.dcbits, z = 1, e = 0x0100u, z2 = 0;
-        bool live = cur.valid && cur.have && cur.dcbits != ZJ_DC_BAD; // still has symbols to decode
-        if (cur.valid && !live) status |= cur.have ? 1u : 4u;            // no DC code / no position: bad code / truncated
-        if (live) {
-            row[0] = cur.dc;
-            stage(h0, h1, h2, h3);
-        }
+        const uint32_t dcb = cur.have ? cur.dcbits : ZJ_DC_BAD;
+        const uint32_t pnext = cur.has_next ? cur.pnext : 0xFFFFFFFFu;
+        uint32_t p = cur.p0 + dcb, z = 1, e = 0x0100u, z2 = 0;
+        bool live = cur.valid && dcb != ZJ_DC_BAD;            // still has symbols to decode
+        if (cur.valid && !live) status |= cur.have ? 1u : 4u; // no DC code / no position: bad code / truncated
+        if (live) row[0] = (int16_t)cur.dc;
         uint32_t wa = (cur.p0 >> 7) << 2; // stream word held in slot 0 of the column
         const uint16_t *ac = lut + ((im.acsel >> cur.kb) & 1u) * ZJ_TBL_ENTRIES;
         const ZjCanon *cac = canon + ((im.acsel >> cur.kb) & 1u);
@@ -1007,18 +1012,24 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
                 wa = (p >> 7) << 2;
             }
         }
-        if (cur.valid && cur.have && cur.dcbits != ZJ_DC_BAD) {
+        if (cur.valid && dcb != ZJ_DC_BAD) {
             uint32_t st = 0;
             if (((e >> 8) & 31u) == 0) st = 1u;                        // ZJ_ST_BAD_CODE
             else if ((e & 255u) != 0 && z2 >= 64u) st = 2u;            // ZJ_ST_COEF_OVERFLOW
             if (p > cur.pay) st |= 4u;                                 // ZJ_ST_TRUNCATED
             // a cleanly decoded block ends where the next one begins; if it does not, the position
             // list does not describe the sequential decode
-            if (st == 0u && cur.pnext != 0xFFFFFFFFu && cur.pnext != p) atomicOr(&P.flags[1], 1u);
+            if (st == 0u && pnext != 0xFFFFFFFFu && pnext != p) atomicOr(&P.flags[1], 1u);
             status |= st;
         }
         cur = nxt; nxt = nn;
-        h0 = n0; h1 = n1; h2 = n2; h3 = n3;
+        // Pin the rotation here, where the loads of this round's description are long complete and no store is
+        // in flight: left to itself the compiler copies the registers at the loop's back edge, behind the
+        // stores below, and has to wait there for every outstanding memory operation, stores included.
+        asm volatile("" : "+v"(nxt.p0), "+v"(nxt.pnext), "+v"(nxt.dcbits), "+v"(nxt.dc));
+        // the column is free: the next round's bits go in, and the head registers take the bits after those
+        stage(h0, h1, h2, h3);
+        fetch_head(nxt, h0, h1, h2, h3);
         zj_wave_lds_sync();
         // store: piece q = (row q / 8, sixteen bytes q % 8); the row's block is recomputed from its lane
 #pragma unroll
@@ -1091,6 +1102,16 @@ __constant__ uint64_t zj_zz2nat_bytes[8] = {
     ZJ_NAT8(58, 59, 52, 45, 38, 31, 39, 46), ZJ_NAT8(53, 60, 61, 54, 47, 55, 62, 63),
 };
 
+// Stores through a pointer that was itself read from memory (the table of output buffers): the
+// compiler cannot see that it points to global memory and would use flat instructions, which also
+// count as LDS operations and so tie every LDS wait to the pixel stores.
+typedef uint32_t zj_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void zj_store_global16(uint8_t *p, const uint4 &v)
+{
+    *(__attribute__((address_space(1))) zj_u32x4 *)p = zj_u32x4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void zj_store_global1(uint8_t *p, uint8_t v) { *(__attribute__((address_space(1))) uint8_t *)p = v; }
+
 typedef float zj_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short zj_u16x2 __attribute__((ext_vector_type(2)));
 
@@ -1113,11 +1134,14 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
     constexpr int NIT = (NTASK + 63) / 64;
     constexpr int NW = MW * 3 / 4;        // packed RGB words per lane and task
     constexpr int PIECES = ROWB / 16;
+    // the few descriptor fields of the loop, read once (through the reference they would be read again,
+    // and waited for, after every store)
+    const uint32_t im_first_block = im.first_block, im_h = im.h, im_mcux = im.mcux, im_strips_x = im.strips_x, im_w = im.w;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float *blk = blk_all + wave * (ZJ_K2_WBLOCKS * ZJ_K2_BSTRIDE);
     uint8_t *rgb = P.rgb[ii];
     if (rgb == nullptr) return;
-    const size_t stride = P.rgb_stride[ii] ? P.rgb_stride[ii] : (size_t)im.w * 3u;
+    const size_t stride = P.rgb_stride[ii] ? P.rgb_stride[ii] : (size_t)im_w * 3u;
     const bool vec_ok = (((uintptr_t)rgb | stride) & 15u) == 0;
 
     const uint32_t part = lane & 7u; // a lane keeps the same eighth of a block in all its tasks
@@ -1131,11 +1155,11 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
     const uint4 *qpart = reinterpret_cast<const uint4 *>(qlds) + part;
 
     auto strip_src = [&](uint32_t strip, uint32_t &nbw) -> const int16_t * {
-        const uint32_t my = strip / im.strips_x, sx = strip % im.strips_x;
+        const uint32_t my = strip / im_strips_x, sx = strip % im_strips_x;
         const uint32_t x0 = sx * T + wave * TW; // first MCU of this wavefront
-        const uint32_t nm = x0 < im.mcux ? min((uint32_t)TW, im.mcux - x0) : 0u;
+        const uint32_t nm = x0 < im_mcux ? min((uint32_t)TW, im_mcux - x0) : 0u;
         nbw = nm * BPM;
-        return P.qcoef + ((size_t)im.first_block + ((size_t)my * im.mcux + x0) * BPM) * 64u;
+        return P.qcoef + ((size_t)im_first_block + ((size_t)my * im_mcux + x0) * BPM) * 64u;
     };
     auto load3 = [&](const int16_t *src, uint32_t nbw, uint4 (&v)[3]) {
 #pragma unroll
@@ -1153,7 +1177,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
         load3(src, nbw, v);
     }
     for (uint32_t strip = strip0; strip < strip1; strip++) {
-        const uint32_t my = strip / im.strips_x, sx = strip % im.strips_x;
+        const uint32_t my = strip / im_strips_x, sx = strip % im_strips_x;
         const uint32_t x0 = sx * T + wave * TW;
         // phase 1: dequantise (i16 wrapping, both operands in zig-zag order, src/decoder.rs:179-184) two
         // coefficients per instruction, de-zigzag into LDS as f32 (exact), src/decoder.rs:296-300
@@ -1268,9 +1292,14 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
             }
         }
         zj_wave_lds_sync();
+        // The next strip's coefficients, requested in phase 1, have long arrived: take them over here, before
+        // the pixel stores are issued.  Otherwise the first use at the top of the next iteration is where the
+        // wait goes, and there it also covers the stores just issued.
+#pragma unroll
+        for (int i = 0; i < 3; i++) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
         const uint32_t xb = x0 * MW * 3u; // byte offset of the tile inside the pixel row
-        const uint32_t row_valid = min((uint32_t)ROWB, (im.w - min(im.w, x0 * MW)) * 3u); // bytes inside the image
-        const uint32_t rows_valid = min((uint32_t)MH, im.h - min(im.h, my * MH));
+        const uint32_t row_valid = min((uint32_t)ROWB, (im_w - min(im_w, x0 * MW)) * 3u); // bytes inside the image
+        const uint32_t rows_valid = min((uint32_t)MH, im_h - min(im_h, my * MH));
         for (uint32_t q = lane; q < (uint32_t)(PIECES * MH); q += 64u) {
             const uint32_t r = q / PIECES, pc = q % PIECES;
             const uint32_t o = pc * 16u;
@@ -1278,11 +1307,11 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
             uint8_t *dst = rgb + (size_t)(my * MH + r) * stride + xb + o;
             const uint4 pv = *reinterpret_cast<const uint4 *>(stage + r * ROWP + o);
             if (vec_ok && o + 16u <= row_valid) {
-                *reinterpret_cast<uint4 *>(dst) = pv;
+                zj_store_global16(dst, pv);
             } else {
                 const uint32_t s4[4] = {pv.x, pv.y, pv.z, pv.w};
                 const uint32_t nbytes = min(16u, row_valid - o);
-                for (uint32_t i = 0; i < nbytes; i++) dst[i] = (uint8_t)(s4[i >> 2] >> (8u * (i & 3u)));
+                for (uint32_t i = 0; i < nbytes; i++) zj_store_global1(dst + i, (uint8_t)(s4[i >> 2] >> (8u * (i & 3u))));
             }
         }
         zj_wave_lds_sync(); // the block area is reused by the next strip
@@ -1298,7 +1327,7 @@ __global__ __launch_bounds__(256) void zj_k2_idct_rgb(ZjParams P, uint32_t first
     __shared__ __attribute__((aligned(16))) uint16_t qlds[3 * 64];
     const uint32_t grp = P.strip_img[first + blockIdx.x]; // image in the high bits is looked up below
     const uint32_t ii = P.strip_img_img[first + blockIdx.x];
-    const ZjImgDev &im = P.imgs[ii];
+    const ZjImgDev &im = P.imgs[ii]; // a reference on purpose: a copy costs this kernel registers and with them a wavefront per SIMD
     if (threadIdx.x < 192u) qlds[threadIdx.x] = P.qts[im.qt_off[threadIdx.x >> 6] + (threadIdx.x & 63u)];
     __syncthreads();
     const uint32_t nstrips = im.strips_x * im.mcuy;
@@ -1318,7 +1347,7 @@ __global__ __launch_bounds__(256) void zj_k2_idct_gray(ZjParams P, uint32_t firs
     __shared__ __attribute__((aligned(16))) uint16_t qlds[64];
     const uint32_t grp = P.strip_img[first + blockIdx.x];
     const uint32_t ii = P.strip_img_img[first + blockIdx.x];
-    const ZjImgDev &im = P.imgs[ii];
+    const ZjImgDev &im = P.imgs[ii]; // a reference on purpose: a copy costs this kernel registers and with them a wavefront per SIMD
     if (threadIdx.x < 64u) qlds[threadIdx.x] = P.qts[im.qt_off[0] + threadIdx.x];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1505,7 +1534,7 @@ __global__ __launch_bounds__(256) void zj_km_scan(ZjMarkParams M)
 // dqcoef[b][nat] = qcoef[b][zz] * q[zz]: the reference's `blocks` entry (src/decoder.rs:237-240).
 __global__ __launch_bounds__(256) void zj_kx_dequant(ZjParams P, uint32_t ii, int16_t *dst)
 {
-    const ZjImgDev &im = P.imgs[ii];
+    const ZjImgDev im = P.imgs[ii]; // by value: a reference would be read again after every store
     const size_t idx = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (idx >= (size_t)im.nblocks * 64u) return;
     const uint32_t b = (uint32_t)(idx >> 6), zz = (uint32_t)(idx & 63u);

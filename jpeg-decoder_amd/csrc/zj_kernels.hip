@@ -190,7 +190,7 @@ __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *str
         const uint32_t taken = bits.words_done(col) + 1u;
         uint32_t w[ZJ_WIN_WORDS];
 #pragma unroll
-        for (int i = 0; i < ZJ_WIN_WORDS; i++) w[i] = reinterpret_cast<volatile uint32_t *>(col)[i * 64];
+        for (int i = 0; i < ZJ_WIN_WORDS; i++) w[i] = ((volatile __attribute__((address_space(3))) uint32_t *)col)[i * 64]; // LDS reads, said so: a volatile access through a plain pointer becomes a flat load
 #pragma unroll
         for (int i = 0; i < ZJ_WIN_WORDS; i++) {
             w[i] = (uint32_t)i < taken ? w[i] : 0u;

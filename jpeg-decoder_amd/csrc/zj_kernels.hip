@@ -1071,14 +1071,23 @@ __device__ __forceinline__ constexpr uint32_t zj_cos_bits(int n, int k)
 }
 
 // src/dct.rs:87-99: out[n] = 0.5 * fma(in7, C[n][7], ... fma(in0, C[n][0], 0.0)), ascending k.
+// Outputs n and 7 - n are computed together, two to an instruction (v_pk_fma_f32): each half is the same
+// IEEE fused multiply-add, in the same order, as the scalar chain.  C[7-n][k] = (-1)^k C[n][k], so the
+// two coefficients of a step differ at most in sign.
+typedef float zj_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void zj_idct_1d(const float (&in)[8], float (&out)[8])
 {
 #pragma unroll
-    for (int n = 0; n < 8; n++) {
-        float s = 0.0f;
+    for (int n = 0; n < 4; n++) {
+        zj_f32x2 s = {0.0f, 0.0f};
 #pragma unroll
-        for (int k = 0; k < 8; k++) s = __builtin_fmaf(in[k], __uint_as_float(zj_cos_bits(n, k)), s);
-        out[n] = s * 0.5f;
+        for (int k = 0; k < 8; k++) {
+            const zj_f32x2 c = {__uint_as_float(zj_cos_bits(n, k)), __uint_as_float(zj_cos_bits(7 - n, k))};
+            s = __builtin_elementwise_fma(zj_f32x2{in[k], in[k]}, c, s);
+        }
+        s = s * zj_f32x2{0.5f, 0.5f};
+        out[n] = s.x;
+        out[7 - n] = s.y;
     }
 }
 
@@ -1112,7 +1121,6 @@ __device__ __forceinline__ void zj_store_global16(uint8_t *p, const uint4 &v)
 }
 __device__ __forceinline__ void zj_store_global1(uint8_t *p, uint8_t v) { *(__attribute__((address_space(1))) uint8_t *)p = v; }
 
-typedef float zj_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short zj_u16x2 __attribute__((ext_vector_type(2)));
 
 #define ZJ_K2_BLOCKS 96   // blocks per strip (one workgroup pass): 16 MCUs of 4:2:0, 32 of 4:4:4, 24 of 4:2:2 / 4:4:0

@@ -6,6 +6,7 @@
 //   k1a_sync     one lane per fixed-size bitstream subsequence, one wavefront per 64 of them;
 //                lanes decode from a guessed state and keep decoding into their neighbours'
 //                subsequences until their state meets the recorded one (self-synchronisation)
+//                (k1a_sync_packed: the same for short segments that share a wavefront, a lane group each)
 //   k1b_fix      stitches consecutive wavefront chunks the same way, one lane per chunk boundary
 //   k1s_scan     exclusive prefix sum of blocks-per-subsequence inside each segment
 //   k1p_positions  turns the block-start bitmap left by the walks into the list of block positions
@@ -15,6 +16,7 @@
 // Stage 2+3 (src/decoder.rs:179-184 dequantize, :137-146 de-zigzag, src/dct.rs IDCT,
 // src/decoder.rs:265-320 colour + store):
 //   k2_idct_rgb  LDS-staged column pass / row pass, chroma replication, YCbCr->RGB, coalesced store
+// Batch planning: km_markers / km_scan find the restart markers in the uploaded scans.
 // Everything floating point keeps the reference's operation order; the file is compiled with
 // -ffp-contract=off so that only the explicit fmaf chains of the IDCT are fused (src/dct.rs:95).
 #include <hip/hip_runtime.h>

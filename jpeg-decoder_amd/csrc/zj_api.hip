@@ -411,7 +411,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             d.first_k1w = (uint32_t)k1w_img.size();
             for (uint64_t m = 0; m < nmcu; m += per_wg) k1w_img.push_back((uint32_t)i);
         }
-        const uint32_t T = 96 / d.bpm;
+        const uint32_t T = ncomp == 1 ? 96u : 4u * zj_k2_wave_mcus(d.hs, d.vs); // MCUs per strip of stage 2
         d.strips_x = (d.mcux + T - 1) / T;
         const uint32_t ns = (d.strips_x * d.mcuy + ZJ_K2_NS - 1) / ZJ_K2_NS; // workgroups of stage 2
         const int cls = ncomp == 1 ? 4 : (d.hs == 2 && d.vs == 2) ? 0 : (d.hs == 1 && d.vs == 1) ? 1 : (d.hs == 2) ? 2 : 3;

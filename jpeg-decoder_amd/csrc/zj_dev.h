@@ -56,6 +56,9 @@ struct ZjParams {
 };
 
 #define ZJ_K2_NS 4 // strips per workgroup of the IDCT/colour kernel
+// MCUs of a strip that one wavefront of the IDCT/colour kernel takes (a strip is four times that): chosen so
+// that (MCUs) x (pixel rows of an MCU) = 64, one (pixel row, MCU) task per lane.  One-component frames: 24.
+__host__ __device__ constexpr uint32_t zj_k2_wave_mcus(uint32_t hs, uint32_t vs) { return vs == 2u ? 4u : 8u; }
 #define ZJ_K2_CLASSES 5
 #define ZJ_UNSTUFF_TILE 15872u // raw bytes per workgroup of the unstuff pass: 128 threads x 31 words
 

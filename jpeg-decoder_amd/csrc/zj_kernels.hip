@@ -1125,7 +1125,7 @@ __device__ __forceinline__ void zj_store_global1(uint8_t *p, uint8_t v) { *(__at
 
 typedef unsigned short zj_u16x2 __attribute__((ext_vector_type(2)));
 
-#define ZJ_K2_BLOCKS 96   // blocks per strip (one workgroup pass): 16 MCUs of 4:2:0, 32 of 4:4:4, 24 of 4:2:2 / 4:4:0
+#define ZJ_K2_BLOCKS 96   // blocks per strip of a one-component frame (one workgroup pass); colour layouts: zj_k2_wave_mcus
 #define ZJ_K2_WBLOCKS 24  // of which each wavefront takes a quarter and works on it without workgroup barriers
 #define ZJ_K2_BSTRIDE 72  // floats per block in LDS: 64 + 8 keeps the column pass conflict-free
 // ZJ_K2_NS (zj_dev.h) strips per workgroup; the next strip's coefficients are fetched while this one computes
@@ -1135,8 +1135,10 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
                                            uint32_t strip1, float *blk_all, const uint16_t *qlds)
 {
     constexpr int BPM = HS * VS + 2;
-    constexpr int T = ZJ_K2_BLOCKS / BPM; // MCUs per strip
-    constexpr int TW = T / 4;             // MCUs per wavefront
+    constexpr int TW = (int)zj_k2_wave_mcus(HS, VS); // MCUs per wavefront: TW * MH = 64 tasks in phase 3
+    constexpr int T = 4 * TW;                        // MCUs per strip
+    constexpr int WB = TW * BPM;                     // blocks per wavefront: 24 (4:2:0, 4:4:4), 32 (4:2:2), 16 (4:4:0)
+    constexpr int NLD = WB / 8;                      // 16-byte pieces of coefficients per lane
     constexpr int MW = 8 * HS, MH = 8 * VS;
     constexpr int ROWB = TW * MW * 3;     // bytes of one pixel row of the wavefront's tile
     constexpr int ROWP = ROWB + 16;       // row pitch of the staged rows: spreads the rows over the banks
@@ -1148,7 +1150,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
     // and waited for, after every store)
     const uint32_t im_first_block = im.first_block, im_h = im.h, im_mcux = im.mcux, im_strips_x = im.strips_x, im_w = im.w;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    float *blk = blk_all + wave * (ZJ_K2_WBLOCKS * ZJ_K2_BSTRIDE);
+    float *blk = blk_all + wave * (WB * ZJ_K2_BSTRIDE);
     uint8_t *rgb = P.rgb[ii];
     if (rgb == nullptr) return;
     const size_t stride = P.rgb_stride[ii] ? P.rgb_stride[ii] : (size_t)im_w * 3u;
@@ -1171,16 +1173,16 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
         nbw = nm * BPM;
         return P.qcoef + ((size_t)im_first_block + ((size_t)my * im_mcux + x0) * BPM) * 64u;
     };
-    auto load3 = [&](const int16_t *src, uint32_t nbw, uint4 (&v)[3]) {
+    auto load3 = [&](const int16_t *src, uint32_t nbw, uint4 (&v)[NLD]) {
 #pragma unroll
-        for (uint32_t i = 0; i < 3u; i++) {
+        for (uint32_t i = 0; i < (uint32_t)NLD; i++) {
             const uint32_t q = lane + i * 64u;
             v[i] = make_uint4(0, 0, 0, 0);
             if ((q >> 3) < nbw) v[i] = *reinterpret_cast<const uint4 *>(src + (size_t)q * 8u);
         }
     };
 
-    uint4 v[3];
+    uint4 v[NLD];
     uint32_t nbw;
     {
         const int16_t *src = strip_src(strip0, nbw);
@@ -1192,7 +1194,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
         // phase 1: dequantise (i16 wrapping, both operands in zig-zag order, src/decoder.rs:179-184) two
         // coefficients per instruction, de-zigzag into LDS as f32 (exact), src/decoder.rs:296-300
 #pragma unroll
-        for (uint32_t i = 0; i < 3u; i++) {
+        for (uint32_t i = 0; i < (uint32_t)NLD; i++) {
             const uint32_t b = (lane + i * 64u) >> 3;
             const uint32_t kb = b % BPM;
             const uint32_t comp = kb < (uint32_t)(HS * VS) ? 0u : (kb == (uint32_t)(HS * VS) ? 1u : 2u);
@@ -1215,7 +1217,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
         zj_wave_lds_sync();
         // phase 2: 1-D IDCT over the columns of every block, in place (src/dct.rs:104-111)
 #pragma unroll
-        for (uint32_t i = 0; i < 3u; i++) {
+        for (uint32_t i = 0; i < (uint32_t)NLD; i++) {
             const uint32_t q = lane + i * 64u;
             const uint32_t b = q >> 3, col = q & 7u;
             float *bp = blk + b * ZJ_K2_BSTRIDE + col;
@@ -1306,7 +1308,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
         // the pixel stores are issued.  Otherwise the first use at the top of the next iteration is where the
         // wait goes, and there it also covers the stores just issued.
 #pragma unroll
-        for (int i = 0; i < 3; i++) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
+        for (int i = 0; i < NLD; i++) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
         const uint32_t xb = x0 * MW * 3u; // byte offset of the tile inside the pixel row
         const uint32_t row_valid = min((uint32_t)ROWB, (im_w - min(im_w, x0 * MW)) * 3u); // bytes inside the image
         const uint32_t rows_valid = min((uint32_t)MH, im_h - min(im_h, my * MH));
@@ -1333,7 +1335,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
 template <int HS, int VS>
 __global__ __launch_bounds__(256) void zj_k2_idct_rgb(ZjParams P, uint32_t first)
 {
-    __shared__ __attribute__((aligned(16))) float blk[ZJ_K2_BLOCKS * ZJ_K2_BSTRIDE];
+    __shared__ __attribute__((aligned(16))) float blk[4u * zj_k2_wave_mcus(HS, VS) * (HS * VS + 2) * ZJ_K2_BSTRIDE];
     __shared__ __attribute__((aligned(16))) uint16_t qlds[3 * 64];
     const uint32_t grp = P.strip_img[first + blockIdx.x]; // image in the high bits is looked up below
     const uint32_t ii = P.strip_img_img[first + blockIdx.x];

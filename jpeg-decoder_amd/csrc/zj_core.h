@@ -333,13 +333,30 @@ ZJ_HD uint32_t zj_walk_entry(uint32_t e, bool isdc)
     return (len + sbits) | (zadv << 6);
 }
 
+// First-level entry for the next bits of the stream.  LDS = true says the table is in LDS (kernels only):
+// the entry's address is then formed by one shift-and-add; left to the compiler, (x >> 23) << 1 becomes a
+// shift, a mask and an add, in a loop that runs once per Huffman symbol.
+template <bool LDS>
+ZJ_HD uint32_t zj_tbl_first(const uint16_t *tbl, uint32_t top32)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (LDS) {
+        const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint16_t *)tbl;
+        uint32_t addr;
+        asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(addr) : "v"(top32 >> (32 - ZJ_L1_BITS)), "v"(base));
+        return *(const __attribute__((address_space(3))) uint16_t *)(uintptr_t)addr;
+    }
+#endif
+    return tbl[top32 >> (32 - ZJ_L1_BITS)];
+}
+
 // wtbl: one table of walk entries (ZJ_TBL_ENTRIES entries).
 // CANON = false is for table sets whose long codes all fit the second level (the batch planner knows):
 // the loop then contains no call.
-template <bool CANON = true>
+template <bool CANON = true, bool LDS = false>
 ZJ_HD uint32_t zj_lookup_walk(const uint16_t *wtbl, const ZjCanon *canon, uint32_t top32, bool isdc)
 {
-    uint32_t e = wtbl[top32 >> (32 - ZJ_L1_BITS)];
+    uint32_t e = zj_tbl_first<LDS>(wtbl, top32);
     if (e & 0x8000u) {
         const uint32_t nb = (e >> 12) & 7u;
         if (CANON && nb == 0) return zj_walk_entry(zj_canon_lookup(canon, top32), isdc);
@@ -349,10 +366,10 @@ ZJ_HD uint32_t zj_lookup_walk(const uint16_t *wtbl, const ZjCanon *canon, uint32
 }
 
 // tbl: one table (ZJ_TBL_ENTRIES entries).  Returns [12:8] length, [7:0] symbol; length 0 = invalid.
-template <bool CANON = true>
+template <bool CANON = true, bool LDS = false>
 ZJ_HD uint32_t zj_lookup(const uint16_t *tbl, const ZjCanon *canon, uint32_t top32)
 {
-    uint32_t e = tbl[top32 >> (32 - ZJ_L1_BITS)];
+    uint32_t e = zj_tbl_first<LDS>(tbl, top32);
     if (e & 0x8000u) {
         uint32_t nb = (e >> 12) & 7u;
         if (CANON && nb == 0) return zj_canon_lookup(canon, top32);
@@ -429,8 +446,8 @@ struct ZjEmitWords { // bitmap words addressed directly (host side, and the one-
 
 // Walk the symbols that START inside [st.p, stop) -- the serial loop of src/decoder.rs:194-235 seen
 // as a state machine over (bit position, block in MCU, zig-zag index) -- on a reader that is already
-// positioned at st.p.  `wlut` is a table set of walk entries.
-template <class BITS, class EMIT, bool CANON = true>
+// positioned at st.p.  `wlut` is a table set of walk entries (LDS = true: in LDS, see zj_tbl_first).
+template <class BITS, class EMIT, bool CANON = true, bool LDS = false>
 ZJ_HD void zj_decode_run(BITS &bits, const uint16_t *wlut, const ZjCanon *canon, uint32_t selw, uint32_t bpm,
                          ZjState &st, uint32_t stop, EMIT &em)
 {
@@ -441,7 +458,7 @@ ZJ_HD void zj_decode_run(BITS &bits, const uint16_t *wlut, const ZjCanon *canon,
         const uint32_t top = bits.top32();
         const bool isdc = (z == 0);
         const uint32_t t = (selw >> (2u * b + (isdc ? 0u : 16u))) & 3u;
-        const uint32_t e = zj_lookup_walk<CANON>(wlut + t * ZJ_TBL_ENTRIES, canon ? canon + t : nullptr, top, t < 2u);
+        const uint32_t e = zj_lookup_walk<CANON, LDS>(wlut + t * ZJ_TBL_ENTRIES, canon ? canon + t : nullptr, top, t < 2u);
         const uint32_t tot = e & 63u;
         em.block_start(p, isdc ? 1u : 0u);
         const uint32_t z2 = z + ((e >> 6) & 127u);

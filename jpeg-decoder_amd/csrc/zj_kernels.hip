@@ -186,7 +186,7 @@ __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *str
         if (!primed) { bits.init(col, wbase, st.p); primed = true; }
         else bits.rebase(col, wbase, st.p);
         const uint32_t wend = (win + 1u) * ZJ_WIN_BITS;
-        zj_decode_run<ZjBitsLds, ZjBitsLds, CANON>(bits, lut, canon, selw, bpm, st, wend < end ? wend : end, bits);
+        zj_decode_run<ZjBitsLds, ZjBitsLds, CANON, true>(bits, lut, canon, selw, bpm, st, wend < end ? wend : end, bits);
         // slots up to the reader's current word hold bitmap words, the ones behind it still stream words
         bits.slot[0] = bits.bm;
         const uint32_t taken = bits.words_done(col) + 1u;
@@ -982,7 +982,7 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
                 auto turn = [&](auto with_canon) -> bool {
                     const uint32_t top = (uint32_t)(((((uint64_t)w0 << 32) | w1) << o) >> 32);
                     const uint32_t wn = slot[128];
-                    e = zj_lookup<decltype(with_canon)::value>(ac, cac, top);
+                    e = zj_lookup<decltype(with_canon)::value, true>(ac, cac, top);
                     const uint32_t len = (e >> 8) & 31u, sz = e & 15u;
                     z2 = z + ((e >> 4) & 15u);                 // src/decoder.rs:225
                     const bool eob = (e & 255u) == 0;          // :212 (a pattern that is no code reads as 0 too)

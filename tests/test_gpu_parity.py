@@ -128,6 +128,42 @@ def test_edge_sizes(ctx):
         assert_same(data, rgb[0], st[0], coef[0])
 
 
+def test_output_pitch_and_alignment(ctx):
+    """Caller-chosen output buffers: a tight pitch of 3 * width bytes that is no multiple of 16, a buffer that
+    starts at an odd address, and a wide pitch -- every sampling layout and one-component frames.  Bytes
+    outside the image's rows must stay untouched."""
+    import torch
+    cases = [(101, 37, 2, 2), (67, 50, 1, 1), (130, 23, 2, 1), (45, 70, 1, 2), (77, 29, 0, 0), (1921, 40, 2, 2)]
+    files = [synth.encode(w, h, hs, vs, 90, 0, 60 + i, 0) for i, (w, h, hs, vs) in enumerate(cases)]
+    imgs = [J.ParsedImage(f) for f in files]
+    refs = [oracle.decode(f).rgb for f in files]
+    for mode in ("tight", "odd", "wide"):
+        b = J.Batch(ctx, imgs)
+        bufs, outs = [], []
+        for im in imgs:
+            row = im.width * 3
+            pitch = row if mode == "tight" else (row + 5 if mode == "odd" else (row + 63) // 16 * 16 + 16)
+            off = 3 if mode == "odd" else 0
+            buf = torch.full((off + im.height * pitch + 64,), 0xA5, dtype=torch.uint8, device="cuda:0")
+            bufs.append(buf)
+            outs.append(torch.as_strided(buf, (im.height, pitch), (pitch, 1), off))
+        b.decode(outs)
+        st = b.finish()
+        assert not st.any()
+        for i, im in enumerate(imgs):
+            row = im.width * 3
+            host = bufs[i].cpu().numpy()
+            pitch = outs[i].stride(0)
+            off = outs[i].storage_offset()
+            got = np.stack([host[off + y * pitch: off + y * pitch + row] for y in range(im.height)]).reshape(im.height, im.width, 3)
+            assert np.array_equal(got, refs[i]), (mode, i)
+            mask = np.ones(host.shape, bool)
+            for y in range(im.height):
+                mask[off + y * pitch: off + y * pitch + row] = False
+            assert (host[mask] == 0xA5).all(), (mode, i)
+        b.close()
+
+
 def test_content_classes_1080p(ctx):
     """Full-size 1080p 4:2:0 and 4:4:4 images of all three content classes (smooth streams have many
     blocks per subsequence, noise streams few)."""

@@ -164,6 +164,30 @@ def test_no_gpu_is_a_loud_error():
     assert e.value.kind == "device"
 
 
+def test_null_handles_are_errors_not_crashes():
+    """Nothing unwinds or faults across the C ABI: calls on missing handles return an error code, a null
+    pointer or zero (the reference panics instead, src/decoder.rs:358 and the unwraps around it)."""
+    L = B.lib()
+    st = (C.c_uint32 * 1)()
+    ms = (C.c_float * B.ZJ_NUM_KERNELS)()
+    v = [C.c_uint64() for _ in range(4)]
+    assert not L.zj_batch_create(None, None, 0, 0)
+    assert L.zj_batch_decode(None, None, None) == B.ZJ_E_INVALID
+    assert L.zj_batch_finish(None, st) == B.ZJ_E_INVALID
+    assert not L.zj_batch_qcoef(None, 0)
+    assert L.zj_batch_export_coef(None, 0, None, None, B.ZJ_MEM_HOST) == B.ZJ_E_INVALID
+    assert L.zj_batch_segments(None, 0, None, 0) == 0
+    assert L.zj_batch_set_profiling(None, 1) == B.ZJ_E_INVALID
+    assert L.zj_batch_kernel_times(None, ms) == B.ZJ_E_INVALID
+    assert L.zj_batch_bytes(None, *[C.byref(x) for x in v]) == B.ZJ_E_INVALID
+    assert L.zj_decode_batch(None, None, 0, None, st) == B.ZJ_E_INVALID
+    assert L.zj_last_error(None) == b"no context"
+    L.zj_batch_destroy(None)
+    L.zj_destroy(None)
+    assert L.zj_kernel_name(-1) == b"" and L.zj_kernel_name(B.ZJ_NUM_KERNELS) == b""
+    assert L.zj_write_ppm(None, 1, 1, None, 0) == B.ZJ_E_INVALID
+
+
 def test_ac_value_fast_form_equals_extend():
     """The compare-free EXTEND used by the block writer equals the reference form (src/ec.rs sign_code) for
     every AC size 0..15: all value patterns of the size, with random bits behind them."""

@@ -227,6 +227,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     std::vector<size_t> raw_off(n, 0);
     size_t raw_total = 0, ust_total = 0;
     uint64_t nsub_total = 0, nblk_total = 0, nstrip_total = 0;
+    uint32_t prev_lut_set = ZJ_NONE;
     std::vector<size_t> offs;
 
     // The scans go to the device first: the restart markers are searched there.
@@ -259,7 +260,6 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
         ZjImgDev &d = b->imgs[i];
         memset(&d, 0, sizeof d);
         d.first_seg = (uint32_t)b->segs.size();
-        d.first_sub = (uint32_t)nsub_total;
         d.first_block = (uint32_t)nblk_total;
         d.first_strip = (uint32_t)nstrip_total;
         if (!zj_image_supported(&im)) { b->unsupported[i] = 1; continue; }
@@ -336,6 +336,15 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             nint = zj_restart_offsets(&im, offs.data(), offs.size());
             if (nint > offs.size()) nint = offs.size();
         }
+        // The workgroups of the sync and fix passes take four chunks each and load one table set: an image
+        // starts a new workgroup only when its table set differs from its predecessor's.  (Padding every
+        // image to whole workgroups left half of all wavefront slots empty for images of two chunks.)
+        if (d.lut_set != prev_lut_set) {
+            while (chunk_seg.size() % 4u) chunk_seg.push_back(ZJ_NONE);
+            nsub_total = align_up(nsub_total, 256);
+            prev_lut_set = d.lut_set;
+        }
+        d.first_sub = (uint32_t)nsub_total;
         uint32_t sub_in_img = 0;
         uint32_t open_lanes = 0, open_used = 0; // the packed chunk under construction: its group size, lanes taken
         // Bits per lane wanted in the groups of short segments.  A lone wavefront needs about 20 us per
@@ -400,8 +409,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             b->segs.push_back(s);
         }
         sub_in_img = (uint32_t)align_up(sub_in_img, 64);
-        d.nsub = (uint32_t)align_up(sub_in_img, 256);
-        for (uint32_t c = sub_in_img / 64; c < d.nsub / 64; c++) chunk_seg.push_back(ZJ_NONE);
+        d.nsub = sub_in_img;
         nsub_total += d.nsub;
         const uint32_t nb_pad = (uint32_t)align_up(d.nblocks, 256);
         for (uint32_t g = 0; g < nb_pad / 256; g++) blk256_img.push_back((uint32_t)i);
@@ -424,6 +432,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
         if (nsub_total > 0xF0000000ull || nblk_total > 0xF0000000ull || nwin_total > 0xF0000000ull) { ctx->err = "batch too large for 32-bit indices"; delete b; return nullptr; }
     }
 
+    while (chunk_seg.size() % 4u) chunk_seg.push_back(ZJ_NONE); // whole workgroups
     ZjParams &P = b->P;
     bool ok = true;
     P.imgs = dev_upload(b, b->imgs);

@@ -56,8 +56,8 @@ struct ZjImgDev {
     uint32_t hs, vs, bpm;   // luma sampling factors, blocks per MCU (hs*vs + 2)
     uint32_t ri_blocks;     // blocks per restart segment (0 = one segment)
     uint32_t first_seg, nseg;
-    uint32_t first_sub;     // first global subsequence index (multiple of 256)
-    uint32_t nsub;          // subsequence slots of this image (multiple of 256)
+    uint32_t first_sub;     // first global subsequence index (multiple of 64; of 256 where the table set changes)
+    uint32_t nsub;          // subsequence slots of this image (multiple of 64)
     uint32_t first_block;   // first global block index (multiple of 256)
     uint32_t nblocks;
     uint32_t lut_set;       // index into the table-set arena

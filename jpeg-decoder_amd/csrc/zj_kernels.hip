@@ -403,7 +403,7 @@ __global__ __launch_bounds__(ZJ_K0_THREADS) void zj_k0_unstuff(ZjParams P)
 }
 
 // ---------------------------------------------------------------------------------- k1a: sync
-// 256 threads = 4 wavefronts = 4 chunks of 64 subsequences, all of one image (table set in LDS).
+// 256 threads = 4 wavefronts = 4 chunks of 64 subsequences, all with one table set (in LDS), of one image or of neighbours.
 // Round 0: every lane walks its own subsequence from the guessed state "a block starts here" and
 // leaves one record and one set of bitmap words per window.  Round k: lane i walks on into
 // subsequence i+k from the state it carries, replacing the records and bitmap words it passes, until
@@ -553,8 +553,10 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
     __syncthreads();
     const uint32_t seg = P.chunk_seg[chunk];
     if (seg == ZJ_NONE || P.segs[seg].lanes != 64u) return; // wave-uniform: a padding chunk, or one for the packed kernel
-    if (im.flags & 2u) zj_k1a_body<true>(P, im, lut, col, chunk, lane);
-    else zj_k1a_body<false>(P, im, lut, col, chunk, lane);
+    // the four chunks of a workgroup share a table set, not necessarily an image: layout and selectors are the wavefront's own
+    const ZjImgDev imw = P.imgs[P.segs[seg].img];
+    if (imw.flags & 2u) zj_k1a_body<true>(P, imw, lut, col, chunk, lane);
+    else zj_k1a_body<false>(P, imw, lut, col, chunk, lane);
 }
 
 // The same for packed chunks; a kernel of its own so that each form keeps its own register budget
@@ -580,8 +582,9 @@ __global__ __launch_bounds__(256) void zj_k1a_sync_packed(ZjParams P)
     if (seg == ZJ_NONE) return;
     const uint32_t G = P.segs[seg].lanes;
     if (G == 64u) return;
-    if (im.flags & 2u) zj_k1a_body_packed<true>(P, im, lut, col, chunk, seg, G, lane);
-    else zj_k1a_body_packed<false>(P, im, lut, col, chunk, seg, G, lane);
+    const ZjImgDev imw = P.imgs[P.segs[seg].img]; // a packed chunk holds segments of one image
+    if (imw.flags & 2u) zj_k1a_body_packed<true>(P, imw, lut, col, chunk, seg, G, lane);
+    else zj_k1a_body_packed<false>(P, imw, lut, col, chunk, seg, G, lane);
 }
 
 // ---------------------------------------------------------------------------------- k1b: fix
@@ -617,7 +620,8 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
     const uint32_t q0 = chunk * 64u - sg.first_sub;
     if (!sub_active(sg, q0, SB, pay)) return;
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
-    ZjSel sel = {im.bpm, im.dcsel, im.acsel};
+    const ZjImgDev iml = P.imgs[sg.img]; // the chunk's own image: the workgroup shares only the table set
+    ZjSel sel = {iml.bpm, iml.dcsel, iml.acsel};
     const uint32_t selw = zj_selword(sel);
     const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + sg.out_off);
     uint32_t *bitmap = reinterpret_cast<uint32_t *>(P.bitmap + sg.out_off);

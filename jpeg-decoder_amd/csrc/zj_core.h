@@ -69,6 +69,7 @@ struct ZjImgDev {
     uint32_t strips_x;      // strips per MCU row
     uint32_t flags;         // bit 0: supported, bit 1: the table set needs the canonical search for some codes
     uint32_t first_k1w;     // first workgroup of the write pass
+    uint32_t k1w_mcus;      // MCUs per wavefront of the write pass (a multiple of 64)
 };
 
 struct ZjSegDev {

@@ -848,7 +848,8 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan(ZjParams P)
 // first bit, fetched a round ahead), read with the same branch-free two-word reader as the sync pass;
 // a block that outgrows its column waits for the others and is restaged.  The DC symbol is not decoded
 // again: its length comes from the DC pass.
-// MCUs per wavefront: 64 for 4:4:4 (1 luma + 2 chroma rounds), 32 otherwise.
+// MCUs per wavefront: chosen by the planner, a multiple of 64 for 4:4:4 and of 32 otherwise (whole rounds);
+// long runs amortise a wavefront's start (tables into LDS, two dependent trips to memory before the first symbol).
 #define ZJ_K1W_SLOTS 16u
 
 __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
@@ -869,7 +870,7 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
 
     const uint32_t nl = im.hs * im.vs, bpm = im.bpm;
     const uint32_t shl = nl == 4u ? 2u : (nl == 2u ? 1u : 0u);     // log2 of the luma blocks per MCU
-    const uint32_t M = nl == 1u ? 64u : 32u;                       // MCUs per wavefront
+    const uint32_t M = im.k1w_mcus;                                // MCUs per wavefront
     const uint32_t m0 = ((blockIdx.x - im.first_k1w) * 4u + wave) * M; // first MCU of this wavefront
     const uint32_t nmcu = im.nblocks / bpm;
     if (m0 >= nmcu) return; // wave-uniform

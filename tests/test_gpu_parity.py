@@ -226,6 +226,29 @@ def test_batch_of_1080p_is_deterministic_and_uniform(ctx):
     b.close()
 
 
+def test_large_batches_use_long_write_runs(ctx):
+    """From a few hundred thousand MCUs on, the planner gives every wavefront of the write pass longer runs of
+    MCUs (up to eight times the base).  800 images of three layouts, every output compared."""
+    import torch
+    files = [synth.encode(1920, 1080, 2, 2, seed=71), synth.encode(1920, 1080, 1, 1, seed=72), synth.encode(1000, 600, 2, 1, seed=73),
+             synth.encode(1920, 1080, 2, 2, seed=74, restart_interval=120)]
+    refs = [oracle.decode(f) for f in files]
+    pick = [0, 0, 0, 1, 0, 2, 0, 3]
+    imgs = [J.ParsedImage(files[pick[i % 8]]) for i in range(800)]
+    b = J.Batch(ctx, imgs)
+    outs = b.alloc_rgb()
+    b.decode(outs)
+    st = b.finish()
+    assert not st.any()
+    want = [torch.from_numpy(r.rgb).to("cuda:0") for r in refs]
+    for i, im in enumerate(imgs):
+        k = pick[i % 8]
+        assert torch.equal(outs[i][:, : im.width * 3].reshape(im.height, im.width, 3), want[k]), i
+    for i in (0, 3, 5, 7, 799):
+        assert np.array_equal(b.coefficients(i), refs[pick[i % 8]].qcoef)
+    b.close()
+
+
 def test_restart_band_equals_rows_of_full_decode(ctx):
     """The multi-GPU split of one restart-marked image: every band decoded on its own equals the same
     rows of the whole image."""

@@ -53,9 +53,10 @@ struct ZjParams {
     const size_t *rgb_stride;   // [image]
     uint32_t nchunks;
     uint32_t nseg;
+    uint32_t k2_ns;             // strips per workgroup of the IDCT/colour kernel
 };
 
-#define ZJ_K2_NS 4 // strips per workgroup of the IDCT/colour kernel
+#define ZJ_K2_NS 4 // strips per workgroup of the IDCT/colour kernel at least; the planner doubles it up to 16 in large batches (ZjParams::k2_ns)
 // MCUs of a strip that one wavefront of the IDCT/colour kernel takes (a strip is four times that): chosen so
 // that (MCUs) x (pixel rows of an MCU) = 64, one (pixel row, MCU) task per lane.  One-component frames: 24.
 __host__ __device__ constexpr uint32_t zj_k2_wave_mcus(uint32_t hs, uint32_t vs) { return vs == 2u ? 4u : 8u; }

@@ -1133,7 +1133,7 @@ typedef unsigned short zj_u16x2 __attribute__((ext_vector_type(2)));
 #define ZJ_K2_BLOCKS 96   // blocks per strip of a one-component frame (one workgroup pass); colour layouts: zj_k2_wave_mcus
 #define ZJ_K2_WBLOCKS 24  // of which each wavefront takes a quarter and works on it without workgroup barriers
 #define ZJ_K2_BSTRIDE 72  // floats per block in LDS: 64 + 8 keeps the column pass conflict-free
-// ZJ_K2_NS (zj_dev.h) strips per workgroup; the next strip's coefficients are fetched while this one computes
+// P.k2_ns strips per workgroup; the next strip's coefficients are fetched while this one computes
 
 template <int HS, int VS>
 __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im, uint32_t ii, uint32_t strip0,
@@ -1348,8 +1348,8 @@ __global__ __launch_bounds__(256) void zj_k2_idct_rgb(ZjParams P, uint32_t first
     if (threadIdx.x < 192u) qlds[threadIdx.x] = P.qts[im.qt_off[threadIdx.x >> 6] + (threadIdx.x & 63u)];
     __syncthreads();
     const uint32_t nstrips = im.strips_x * im.mcuy;
-    const uint32_t s0 = grp * ZJ_K2_NS;
-    const uint32_t s1 = min(s0 + ZJ_K2_NS, nstrips);
+    const uint32_t s0 = grp * P.k2_ns;
+    const uint32_t s1 = min(s0 + P.k2_ns, nstrips);
     zj_k2_body<HS, VS>(P, im, ii, s0, s1, blk, qlds);
 }
 
@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(256) void zj_k2_idct_gray(ZjParams P, uint32_t firs
     const uint4 qv = reinterpret_cast<const uint4 *>(qlds)[part];
     const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
     const uint32_t nstrips = im.strips_x * im.mcuy;
-    const uint32_t s0 = grp * ZJ_K2_NS, s1 = min(s0 + ZJ_K2_NS, nstrips);
+    const uint32_t s0 = grp * P.k2_ns, s1 = min(s0 + P.k2_ns, nstrips);
     for (uint32_t strip = s0; strip < s1; strip++) {
         const uint32_t my = strip / im.strips_x, sx = strip % im.strips_x;
         const uint32_t x0 = sx * T + wave * TW; // first block of this wavefront in the block row

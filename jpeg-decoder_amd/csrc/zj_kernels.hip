@@ -719,26 +719,69 @@ __global__ __launch_bounds__(256) void zj_k1p_positions(ZjParams P)
 // ---------------------------------------------------------------------------------- k1c: DC differences
 // One lane per block: decode the DC symbol at the recorded block position (src/decoder.rs:194-199
 // without the predictor).  Fully parallel; the tables are read through the cache.
-__global__ __launch_bounds__(256) void zj_k1c_dcdiff(ZjParams P)
+#define ZJ_K1C_NB 4 // groups of 256 blocks per workgroup: a lane has that many independent chains of loads in flight
+__global__ __launch_bounds__(256) void zj_k1c_dcdiff(ZjParams P, uint32_t ngroups)
 {
-    const uint32_t ii = P.blk256_img[blockIdx.x];
-    const ZjImgDev im = P.imgs[ii]; // by value: a reference would be read again after every store
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t gl = g - im.first_block;
-    if (gl >= im.nblocks) return;
-    const uint32_t segi = im.ri_blocks ? gl / im.ri_blocks : 0u;
-    const uint32_t seg = im.first_seg + segi;
-    const uint32_t gs = gl - segi * im.ri_blocks;
-    int32_t d = 0;
-    uint32_t nbits = ZJ_DC_BAD;
-    if (gs < P.seg_found[seg]) {
-        const uint32_t t = (im.dcsel >> (gs % im.bpm)) & 1u;
-        const uint32_t *stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[seg].out_off);
-        d = zj_dc_diff(stream, P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES + t * ZJ_TBL_ENTRIES,
-                       P.canons + (size_t)im.lut_set * 4u + t, P.blockpos[g], &nbits);
+    // The pass is a chain of dependent trips to memory per block (position, stream words, table entry) with
+    // next to no arithmetic, so a lane works on several blocks at once: all positions are requested, then all
+    // stream words, then the tables are consulted.  Loads are unconditional, with indices clamped to block 0
+    // of the group's image, and what they return is ignored where the block does not exist.
+    uint32_t g[ZJ_K1C_NB], pos[ZJ_K1C_NB], tsel[ZJ_K1C_NB], lutset[ZJ_K1C_NB], gs[ZJ_K1C_NB], fnd[ZJ_K1C_NB], first[ZJ_K1C_NB];
+    uint64_t soff[ZJ_K1C_NB];
+    bool ok[ZJ_K1C_NB], inimg[ZJ_K1C_NB];
+#pragma unroll
+    for (int k = 0; k < ZJ_K1C_NB; k++) {
+        const uint32_t grp = blockIdx.x * ZJ_K1C_NB + k;
+        inimg[k] = false; g[k] = 0; tsel[k] = 0; lutset[k] = 0; gs[k] = 0; first[k] = 0;
+        uint32_t seg = 0;
+        if (grp < ngroups) { // uniform
+            const uint32_t ii = P.blk256_img[grp];
+            const ZjImgDev &im = P.imgs[ii];
+            g[k] = grp * 256u + threadIdx.x;
+            const uint32_t gl = g[k] - im.first_block;
+            inimg[k] = gl < im.nblocks;
+            const uint32_t glc = inimg[k] ? gl : 0u;
+            const uint32_t segi = im.ri_blocks ? glc / im.ri_blocks : 0u;
+            seg = im.first_seg + segi;
+            gs[k] = glc - segi * im.ri_blocks;
+            tsel[k] = (im.dcsel >> (gs[k] % im.bpm)) & 1u;
+            lutset[k] = im.lut_set;
+            first[k] = im.first_block;
+        }
+        fnd[k] = P.seg_found[seg];
+        soff[k] = P.segs[seg].out_off;
     }
-    P.dcabs[g] = (int16_t)d; // turned into the predicted value in place by the scan
-    P.dcbits[g] = (uint8_t)nbits;
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t *stream[ZJ_K1C_NB];
+#pragma unroll
+    for (int k = 0; k < ZJ_K1C_NB; k++) {
+        ok[k] = inimg[k] && gs[k] < fnd[k];
+        stream[k] = reinterpret_cast<const uint32_t *>(P.ust + soff[k]);
+        pos[k] = P.blockpos[ok[k] ? g[k] : first[k]];
+    }
+    __builtin_amdgcn_sched_barrier(0); // keep the phases apart: the scheduler would otherwise finish one block's chain before it starts the next
+    uint32_t w0[ZJ_K1C_NB], w1[ZJ_K1C_NB];
+#pragma unroll
+    for (int k = 0; k < ZJ_K1C_NB; k++) {
+        const uint32_t p = ok[k] ? pos[k] : 0u;
+        w0[k] = stream[k][p >> 5];
+        w1[k] = stream[k][(p >> 5) + 1u];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < ZJ_K1C_NB; k++) {
+        int32_t d = 0;
+        uint32_t nbits = ZJ_DC_BAD;
+        if (ok[k]) {
+            const uint32_t two[2] = {w0[k], w1[k]};
+            d = zj_dc_diff(two, P.luts + (size_t)lutset[k] * ZJ_SET_ENTRIES + tsel[k] * ZJ_TBL_ENTRIES,
+                           P.canons + (size_t)lutset[k] * 4u + tsel[k], pos[k] & 31u, &nbits);
+        }
+        if (inimg[k]) {
+            P.dcabs[g[k]] = (int16_t)d; // turned into the predicted value in place by the scan
+            P.dcbits[g[k]] = (uint8_t)nbits;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------- k1d: DC scan
@@ -1581,7 +1624,7 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     if (ev) hipEventRecord(ev[e++], st);
     if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
-    hipLaunchKernelGGL(zj_k1c_dcdiff, dim3(L.nblk256), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(zj_k1c_dcdiff, dim3((L.nblk256 + ZJ_K1C_NB - 1) / ZJ_K1C_NB), dim3(256), 0, st, P, L.nblk256);
     if (L.ndtiles) {
         hipLaunchKernelGGL(zj_k1d_tilesum, dim3(L.ndtiles), dim3(256), 0, st, P);
         hipLaunchKernelGGL(zj_k1d_tilescan, dim3(L.nseg), dim3(256), 0, st, P);
@@ -1609,7 +1652,7 @@ extern "C" void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipS
 {
     hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
     if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(zj_k1c_dcdiff, dim3(L.nblk256), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(zj_k1c_dcdiff, dim3((L.nblk256 + ZJ_K1C_NB - 1) / ZJ_K1C_NB), dim3(256), 0, st, P, L.nblk256);
     if (L.ndtiles) {
         hipLaunchKernelGGL(zj_k1d_tilesum, dim3(L.ndtiles), dim3(256), 0, st, P);
         hipLaunchKernelGGL(zj_k1d_tilescan, dim3(L.nseg), dim3(256), 0, st, P);

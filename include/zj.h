@@ -151,6 +151,28 @@ const char *zj_last_error(zj_ctx *ctx);
 zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *imgs, size_t n, uint32_t flags);
 void zj_batch_destroy(zj_batch *b);
 
+/* ---- workspaces: device memory shared by batches that are decoded one after the other ----
+ * A batch made by zj_batch_create owns every byte it uses, the coefficient arena (128 bytes per block)
+ * included, so a job too large for one batch would have to allocate and free per sub-batch.  A workspace
+ * holds one scratch range -- everything a decode call produces on the way to the pixels: unstuffed streams,
+ * bitmaps, window records, block positions, DC values, quantised coefficients -- that all its batches
+ * share, and `nslots` plan ranges (scans, descriptors, tables, status words), one per batch that is alive at
+ * the same time.  zj_batch_create_in allocates nothing: it uploads through pinned staging on a copy stream of
+ * the workspace's own, so planning and uploading batch k+1 overlaps the decode of batch k, and the first
+ * decode call of a batch makes the decode stream wait for its upload.
+ * Rules: batches of one workspace decode on the context's stream, one after the other (any order); the
+ * coefficients of a batch (zj_batch_qcoef, zj_batch_export_coef) are valid until the next decode call of
+ * any batch of the workspace; a slot may be used again when its previous batch has been destroyed. */
+typedef struct zj_workspace zj_workspace;
+/* Upper bounds of the plan and scratch bytes a batch of these images takes (host only, no GPU needed). */
+int zj_workspace_estimate(const zj_image *imgs, size_t n, size_t *plan_bytes, size_t *scratch_bytes);
+zj_workspace *zj_workspace_create(zj_ctx *ctx, size_t scratch_bytes, size_t plan_bytes, uint32_t nslots);
+void zj_workspace_destroy(zj_workspace *ws); /* after its batches */
+/* As zj_batch_create, in plan slot `slot`.  NULL when the batch does not fit (zj_last_error says which range). */
+zj_batch *zj_batch_create_in(zj_workspace *ws, uint32_t slot, const zj_image *imgs, size_t n, uint32_t flags);
+/* Bytes the batch took from its plan slot and from the shared scratch (0, 0 for zj_batch_create). */
+int zj_batch_memory(zj_batch *b, size_t *plan_bytes, size_t *scratch_bytes);
+
 /* The hot path: stage 1 (unstuff, self-synchronising parallel Huffman decode, DC prefix scan)
  * -> quantised coefficients in the batch's arena; stage 2+3 (dequantise, 8x8 IDCT, chroma
  * upsample, YCbCr->RGB, store) -> rgb[i].  rgb[i] are DEVICE pointers (NULL entries skip stage
@@ -162,6 +184,14 @@ int zj_batch_decode(zj_batch *b, uint8_t *const *rgb, const size_t *stride);
  * reported that subsequence synchronisation had not converged, this call reruns the decode with
  * the exhaustive fix-up loop before returning (never observed on real streams). */
 int zj_batch_finish(zj_batch *b, uint32_t *status);
+
+/* Evidence that decode calls stayed on the fast path, counted over the batch's life:
+ *   counters[0]  times a fix-up lane ran through a whole chunk of subsequences without meeting a record
+ *                that agreed with its state (the condition that sends zj_batch_finish into its loop)
+ *   counters[1]  blocks that did not end where the position list says the next one begins
+ *   counters[2]  zj_batch_finish calls that ran the exhaustive fix-up loop
+ * All three are 0 for every stream seen so far; waits for the stream. */
+int zj_batch_counters(zj_batch *b, uint32_t counters[3]);
 
 /* Device pointer to image i's quantised coefficients inside the arena (valid until destroy). */
 const int16_t *zj_batch_qcoef(zj_batch *b, size_t i);

@@ -57,6 +57,8 @@ _EXPORTS = [
     "zj_batch_export_coef", "zj_batch_set_profiling", "zj_batch_kernel_times", "zj_kernel_name", "zj_batch_bytes",
     "zj_batch_segments",
     "zj_decode_batch",
+    "zj_workspace_estimate", "zj_workspace_create", "zj_workspace_destroy", "zj_batch_create_in", "zj_batch_memory",
+    "zj_batch_counters",
 ]
 
 
@@ -98,6 +100,12 @@ def lib():
     L.zj_batch_bytes.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4; L.zj_batch_bytes.restype = C.c_int
     L.zj_batch_segments.argtypes = [vp, sz, C.POINTER(C.c_uint64), sz]; L.zj_batch_segments.restype = sz
     L.zj_decode_batch.argtypes = [vp, C.POINTER(zj_image), sz, C.POINTER(zj_output), u32p]; L.zj_decode_batch.restype = C.c_int
+    L.zj_workspace_estimate.argtypes = [C.POINTER(zj_image), sz, C.POINTER(sz), C.POINTER(sz)]; L.zj_workspace_estimate.restype = C.c_int
+    L.zj_workspace_create.argtypes = [vp, sz, sz, C.c_uint32]; L.zj_workspace_create.restype = vp
+    L.zj_workspace_destroy.argtypes = [vp]; L.zj_workspace_destroy.restype = None
+    L.zj_batch_create_in.argtypes = [vp, C.c_uint32, C.POINTER(zj_image), sz, C.c_uint32]; L.zj_batch_create_in.restype = vp
+    L.zj_batch_memory.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]; L.zj_batch_memory.restype = C.c_int
+    L.zj_batch_counters.argtypes = [vp, u32p]; L.zj_batch_counters.restype = C.c_int
     _lib = L
     return L
 

@@ -1,10 +1,17 @@
 // zj_api.hip -- the C ABI of include/zj.h on top of the kernels: context, batch planning (all
 // host-side layout decisions, table construction and uploads), the decode call that launches the
 // kernels, result/status retrieval.  The decode call itself allocates nothing.
+//
+// Where a batch's device memory comes from:
+//   * zj_batch_create          every buffer is a hipMalloc of its own, freed by zj_batch_destroy
+//   * zj_batch_create_in       plan memory from one slot of a workspace, scratch from the workspace's
+//                              shared scratch range: no allocation per batch, the coefficient arena and all
+//                              intermediates are reused by the next batch
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -20,6 +27,28 @@ struct zj_ctx {
     hipStream_t stream;
     bool own_stream;
     std::string err;
+    int err_code; // ZJ_E_* behind the last NULL returned by zj_batch_create / zj_batch_create_in / zj_workspace_create
+};
+
+// Device memory a batch takes its buffers from instead of allocating them: a bump allocator over a range
+// the batch does not own.  Offsets advance in multiples of 256 bytes.
+struct ZjPool {
+    uint8_t *base;
+    size_t cap, off;
+};
+
+struct zj_workspace {
+    zj_ctx *ctx;
+    uint8_t *scratch; // shared by every batch of the workspace
+    size_t scratch_bytes;
+    uint8_t *plan; // nslots ranges of plan_bytes each
+    size_t plan_bytes;
+    uint32_t nslots;
+    hipStream_t copy_stream;  // uploads and the marker search of zj_batch_create_in run here
+    uint8_t *stage[2];        // pinned staging chunks for the scan upload
+    hipEvent_t stage_free[2]; // recorded behind the copy that reads stage[k]
+    bool stage_used[2];
+    size_t stage_bytes;
 };
 
 struct zj_batch {
@@ -31,12 +60,26 @@ struct zj_batch {
     ZjParams P;
     ZjLaunch L;
     std::vector<void *> allocs;
-    // pinned staging for the per-call pointer tables
+    // Plan memory (scans, descriptors, tables, status words) belongs to one batch for its whole life; scratch
+    // (everything a decode call produces on the way to the pixels, the coefficient arena included) may be
+    // shared by batches that decode one after the other on one stream.  Either comes from hipMalloc (flag
+    // false) or from a range the batch does not own.
+    bool plan_pooled, scratch_pooled;
+    ZjPool plan_pool, scratch_pool;
+    zj_workspace *ws;  // upload stream and staging of zj_batch_create_in, else NULL
+    hipStream_t up;    // stream of the plan-time uploads and kernels
+    hipEvent_t ready;  // recorded on the workspace's copy stream behind the uploads
+    bool ready_valid, ready_waited;
+    // staging for the per-call pointer tables: pinned, or pageable when the batch may not allocate
+    bool pinned;
     uint8_t **h_rgb;
     size_t *h_stride;
     uint8_t **d_rgb;
     size_t *d_stride;
-    uint32_t *h_flags; // pinned, 4 words
+    uint32_t *h_flags;        // 4 words
+    hipEvent_t tables_copied; // recorded behind the copies that read h_rgb / h_stride
+    bool tables_ev_valid, tables_ev_pending;
+    uint32_t slow_path_calls; // zj_batch_finish calls that had to run the exhaustive fix-up loop
     uint64_t scan_bytes, coef_bytes, rgb_bytes, pixels;
     bool profiling;
     hipEvent_t ev[ZJ_NUM_KERNELS + 1];
@@ -47,9 +90,11 @@ struct zj_batch {
 static bool hip_ok(zj_ctx *c, hipError_t e, const char *what)
 {
     if (e == hipSuccess) return true;
-    if (c) c->err = std::string(what) + ": " + hipGetErrorString(e);
+    if (c) { c->err = std::string(what) + ": " + hipGetErrorString(e); c->err_code = (e == hipErrorOutOfMemory) ? ZJ_E_NOMEM : ZJ_E_DEVICE; }
     return false;
 }
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 extern "C" int zj_device_count(void)
 {
@@ -65,6 +110,7 @@ extern "C" zj_ctx *zj_create(int device, void *stream)
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     zj_ctx *c = new zj_ctx();
     c->device = device;
+    c->err_code = ZJ_OK;
     c->own_stream = (stream == nullptr);
     if (stream) c->stream = (hipStream_t)stream;
     else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
@@ -85,15 +131,42 @@ static const char *k_names[ZJ_NUM_KERNELS] = {"k0_unstuff", "k1a_sync", "k1b_fix
                                               "k1d_dcscan", "k1w_write", "k2_idct_rgb", "total"};
 extern "C" const char *zj_kernel_name(int k) { return (k >= 0 && k < ZJ_NUM_KERNELS) ? k_names[k] : ""; }
 
+enum { ZJ_MEM_PLAN = 0, ZJ_MEM_SCRATCH = 1 };
+
+static void *pool_take(ZjPool &p, size_t bytes)
+{
+    const size_t o = align_up(p.off, 256);
+    if (o > p.cap || bytes > p.cap - o) return nullptr;
+    p.off = o + bytes;
+    return p.base + o;
+}
+
 template <typename T>
-static T *dev_alloc(zj_batch *b, size_t count, bool zero = false)
+static T *dev_alloc(zj_batch *b, size_t count, bool zero = false, int kind = ZJ_MEM_PLAN)
 {
     void *p = nullptr;
     size_t bytes = count * sizeof(T);
     if (bytes == 0) bytes = 16;
-    if (!hip_ok(b->ctx, hipMalloc(&p, bytes), "hipMalloc")) return nullptr;
-    b->allocs.push_back(p);
-    if (zero && !hip_ok(b->ctx, hipMemsetAsync(p, 0, bytes, b->ctx->stream), "hipMemset")) return nullptr;
+    const bool pooled = kind == ZJ_MEM_SCRATCH ? b->scratch_pooled : b->plan_pooled;
+    if (pooled) {
+        ZjPool &pool = kind == ZJ_MEM_SCRATCH ? b->scratch_pool : b->plan_pool;
+        p = pool_take(pool, bytes);
+        if (!p) {
+            char msg[200];
+            snprintf(msg, sizeof msg, "batch does not fit: %s memory of %zu bytes is exhausted (%zu in use, %zu more wanted)",
+                     kind == ZJ_MEM_SCRATCH ? "scratch" : "plan", pool.cap, pool.off, bytes);
+            b->ctx->err = msg;
+            b->ctx->err_code = ZJ_E_NOMEM;
+            return nullptr;
+        }
+        // Shared scratch is not cleared here: another batch may be using it on the decode stream right now.
+        // Nothing in it has to start at zero (the kernels write every word they later read).
+        if (kind == ZJ_MEM_SCRATCH) zero = false;
+    } else {
+        if (!hip_ok(b->ctx, hipMalloc(&p, bytes), "hipMalloc")) return nullptr;
+        b->allocs.push_back(p);
+    }
+    if (zero && !hip_ok(b->ctx, hipMemsetAsync(p, 0, bytes, b->up), "hipMemset")) return nullptr;
     return (T *)p;
 }
 
@@ -102,12 +175,10 @@ static T *dev_upload(zj_batch *b, const std::vector<T> &v)
 {
     T *p = dev_alloc<T>(b, v.size());
     if (!p) return nullptr;
-    if (!v.empty() && !hip_ok(b->ctx, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy H2D"))
-        return nullptr;
+    // synchronous with respect to the host vector (pageable memory is staged before the call returns)
+    if (!v.empty() && !hip_ok(b->ctx, hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, b->up), "hipMemcpy H2D")) return nullptr;
     return p;
 }
-
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Restart markers of every image that has a restart interval, searched on the device in the uploaded
 // scans.  mark_first[i] = index of image i in the lists (ZJ_NONE: no restart interval); per listed image
@@ -133,7 +204,7 @@ static bool find_markers(zj_batch *b, const zj_image *images, size_t n, const ui
         d.out_first = (uint32_t)nout;
         d.cap = (zj_image_mcus(&im) + im.restart_interval - 1) / im.restart_interval;
         nout += d.cap;
-        if (nout > 0xF0000000ull || tile_img.size() + d.ntiles > 0xF0000000ull) { ctx->err = "batch too large for 32-bit indices"; return false; }
+        if (nout > 0xF0000000ull || tile_img.size() + d.ntiles > 0xF0000000ull) { ctx->err = "batch too large for 32-bit indices"; ctx->err_code = ZJ_E_INVALID; return false; }
         mark_first[i] = (uint32_t)mi.size();
         for (uint32_t t = 0; t < d.ntiles; t++) tile_img.push_back((uint32_t)mi.size());
         outfirst.push_back(d.out_first);
@@ -148,12 +219,19 @@ static bool find_markers(zj_batch *b, const zj_image *images, size_t n, const ui
     M.nimgs = (uint32_t)mi.size();
     M.ntiles = (uint32_t)tile_img.size();
     void *d_imgs = nullptr, *d_tile_img = nullptr, *d_tile_count = nullptr, *d_img_count = nullptr, *d_offs = nullptr;
-    hipStream_t st = ctx->stream;
-    bool ok = hip_ok(ctx, hipMalloc(&d_imgs, mi.size() * sizeof(ZjMarkImg)), "hipMalloc") &&
-              hip_ok(ctx, hipMalloc(&d_tile_img, tile_img.size() * 4), "hipMalloc") &&
-              hip_ok(ctx, hipMalloc(&d_tile_count, tile_img.size() * 4), "hipMalloc") &&
-              hip_ok(ctx, hipMalloc(&d_img_count, mi.size() * 4), "hipMalloc") &&
-              hip_ok(ctx, hipMalloc(&d_offs, (size_t)(nout + 1) * 4), "hipMalloc");
+    hipStream_t st = b->up;
+    const size_t sizes[5] = {mi.size() * sizeof(ZjMarkImg), tile_img.size() * 4, tile_img.size() * 4, mi.size() * 4, (size_t)(nout + 1) * 4};
+    void **ptrs[5] = {&d_imgs, &d_tile_img, &d_tile_count, &d_img_count, &d_offs};
+    bool ok = true;
+    const size_t pool_mark = b->plan_pool.off; // pooled: the five buffers are taken from the plan range and given back below
+    for (int k = 0; ok && k < 5; k++) {
+        if (b->plan_pooled) {
+            *ptrs[k] = pool_take(b->plan_pool, sizes[k]);
+            if (!*ptrs[k]) { ctx->err = "batch does not fit: plan memory is exhausted by the restart-marker search"; ctx->err_code = ZJ_E_NOMEM; ok = false; }
+        } else {
+            ok = hip_ok(ctx, hipMalloc(ptrs[k], sizes[k]), "hipMalloc");
+        }
+    }
     if (ok) ok = hip_ok(ctx, hipMemcpyAsync(d_imgs, mi.data(), mi.size() * sizeof(ZjMarkImg), hipMemcpyHostToDevice, st), "H2D marker images") &&
                  hip_ok(ctx, hipMemcpyAsync(d_tile_img, tile_img.data(), tile_img.size() * 4, hipMemcpyHostToDevice, st), "H2D marker tiles");
     if (ok) {
@@ -168,7 +246,8 @@ static bool find_markers(zj_batch *b, const zj_image *images, size_t n, const ui
              (nout == 0 || hip_ok(ctx, hipMemcpyAsync(offs.data(), d_offs, (size_t)nout * 4, hipMemcpyDeviceToHost, st), "D2H marker offsets")) &&
              hip_ok(ctx, hipStreamSynchronize(st), "sync after marker search");
     }
-    (void)hipFree(d_imgs); (void)hipFree(d_tile_img); (void)hipFree(d_tile_count); (void)hipFree(d_img_count); (void)hipFree(d_offs);
+    if (b->plan_pooled) b->plan_pool.off = pool_mark;
+    else { (void)hipFree(d_imgs); (void)hipFree(d_tile_img); (void)hipFree(d_tile_count); (void)hipFree(d_img_count); (void)hipFree(d_offs); }
     return ok;
 }
 
@@ -177,25 +256,96 @@ extern "C" void zj_batch_destroy(zj_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->ws) (void)hipStreamSynchronize(b->ws->copy_stream);
     for (void *p : b->allocs) (void)hipFree(p);
-    if (b->h_rgb) (void)hipHostFree(b->h_rgb);
-    if (b->h_stride) (void)hipHostFree(b->h_stride);
-    if (b->h_flags) (void)hipHostFree(b->h_flags);
+    if (b->pinned) {
+        if (b->h_rgb) (void)hipHostFree(b->h_rgb);
+        if (b->h_stride) (void)hipHostFree(b->h_stride);
+        if (b->h_flags) (void)hipHostFree(b->h_flags);
+    } else {
+        free(b->h_rgb); free(b->h_stride); free(b->h_flags);
+    }
     if (b->ev_valid)
         for (auto &e : b->ev) (void)hipEventDestroy(e);
+    if (b->ready_valid) (void)hipEventDestroy(b->ready);
+    if (b->tables_ev_valid) (void)hipEventDestroy(b->tables_copied);
     delete b;
 }
 
-extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t n, uint32_t flags)
+// Upload of the scans through the workspace's two pinned chunks: the raw arena is built chunk by chunk in
+// pinned memory (scans at their 16-byte aligned offsets, zeros between them) and each chunk goes over in one
+// asynchronous copy while the host fills the other.
+static bool upload_scans_staged(zj_batch *b, const zj_image *images, size_t n, uint8_t *raw, const std::vector<size_t> &raw_off, size_t raw_total)
 {
-    if (!ctx || (!images && n)) return nullptr;
+    zj_workspace *ws = b->ws;
+    zj_ctx *ctx = b->ctx;
+    const size_t CH = ws->stage_bytes;
+    size_t i = 0; // first image that may still have bytes at or behind the chunk's start
+    int k = 0;
+    for (size_t c0 = 0; c0 < raw_total; c0 += CH, k ^= 1) {
+        const size_t c1 = std::min(raw_total, c0 + CH);
+        if (ws->stage_used[k] && !hip_ok(ctx, hipEventSynchronize(ws->stage_free[k]), "staging wait")) return false;
+        uint8_t *dst = ws->stage[k];
+        size_t pos = c0; // everything of the chunk before `pos` is filled
+        while (i < n && pos < c1) {
+            const zj_image &im = images[i];
+            if (!zj_image_supported(&im) || im.scan_len == 0) { i++; continue; }
+            const size_t s0 = raw_off[i], s1 = raw_off[i] + im.scan_len;
+            if (s1 <= pos) { i++; continue; }
+            if (s0 >= c1) break;
+            if (s0 > pos) { memset(dst + (pos - c0), 0, s0 - pos); pos = s0; }
+            const size_t e = std::min(s1, c1);
+            memcpy(dst + (pos - c0), im.scan + (pos - s0), e - pos);
+            pos = e;
+            if (e == s1) i++;
+        }
+        if (pos < c1) memset(dst + (pos - c0), 0, c1 - pos);
+        if (!hip_ok(ctx, hipMemcpyAsync(raw + c0, dst, c1 - c0, hipMemcpyHostToDevice, b->up), "H2D scans")) return false;
+        if (!hip_ok(ctx, hipEventRecord(ws->stage_free[k], b->up), "event record")) return false;
+        ws->stage_used[k] = true;
+    }
+    return hip_ok(ctx, hipMemsetAsync(raw + raw_total, 0, 1040, b->up), "hipMemset");
+}
+
+enum { ZJ_ALLOC_OWN = 0, ZJ_ALLOC_WORKSPACE, ZJ_ALLOC_NONE };
+
+// The planner behind zj_batch_create and zj_batch_create_in.
+// ZJ_ALLOC_NONE: plan and scratch memory both come out of the range [fixed_base, fixed_base + fixed_cap).
+static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n, uint32_t flags, int mode, zj_workspace *ws, uint32_t slot,
+                                   uint8_t *fixed_base, size_t fixed_cap)
+{
+    if (!ctx) return nullptr;
+    ctx->err_code = ZJ_E_INVALID;
+    if (!images && n) { ctx->err = "no images"; return nullptr; }
     if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return nullptr;
     zj_batch *b = new zj_batch();
     b->ctx = ctx;
     b->n = n;
     b->h_rgb = nullptr; b->h_stride = nullptr; b->h_flags = nullptr;
     b->ev_valid = false; b->profiling = false; b->decoded = false;
+    b->ready_valid = false; b->ready_waited = false; b->tables_ev_valid = false; b->tables_ev_pending = false;
+    b->slow_path_calls = 0;
     b->scan_bytes = b->coef_bytes = b->rgb_bytes = b->pixels = 0;
+    b->ws = nullptr;
+    b->up = ctx->stream;
+    b->plan_pooled = b->scratch_pooled = false;
+    b->pinned = true;
+    memset(&b->plan_pool, 0, sizeof b->plan_pool);
+    memset(&b->scratch_pool, 0, sizeof b->scratch_pool);
+    if (mode == ZJ_ALLOC_WORKSPACE) {
+        b->ws = ws;
+        b->up = ws->copy_stream;
+        b->plan_pooled = b->scratch_pooled = true;
+        b->plan_pool = ZjPool{ws->plan + (size_t)slot * ws->plan_bytes, ws->plan_bytes, 0};
+        b->scratch_pool = ZjPool{ws->scratch, ws->scratch_bytes, 0};
+        b->pinned = false;
+    } else if (mode == ZJ_ALLOC_NONE) {
+        // one range for both kinds: plan memory first, scratch behind it (the scratch pool is set up below,
+        // when the plan part is complete)
+        b->plan_pooled = b->scratch_pooled = true;
+        b->plan_pool = ZjPool{fixed_base, fixed_cap, 0};
+        b->pinned = false;
+    }
     memset(&b->P, 0, sizeof b->P);
     memset(&b->L, 0, sizeof b->L);
 
@@ -213,7 +363,7 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
         subbits = 1024;
         while (subbits < 65536u && (uint64_t)subbits * lanes < bits) subbits *= 2u;
     }
-    if (subbits < ZJ_WIN_BITS || subbits > (1u << 20)) { ctx->err = "subsequence bits must be in 512..1048576"; delete b; return nullptr; }
+    if (subbits < ZJ_WIN_BITS || subbits > (1u << 20)) { ctx->err = "subsequence bits must be in 512..1048576"; zj_batch_destroy(b); return nullptr; }
 
     b->imgs.resize(n);
     b->unsupported.assign(n, 0);
@@ -242,13 +392,17 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     if (!raw) { zj_batch_destroy(b); return nullptr; }
     {
         // the entropy-coded bytes as stored, each image at a 16-byte aligned offset
-        bool up = hip_ok(ctx, hipMemsetAsync(raw, 0, raw_total + 1040, ctx->stream), "hipMemset");
-        for (size_t i = 0; up && i < n; i++) {
-            if (!zj_image_supported(&images[i]) || images[i].scan_len == 0) continue;
-            up = hip_ok(ctx, hipMemcpyAsync(raw + raw_off[i], images[i].scan, images[i].scan_len, hipMemcpyHostToDevice, ctx->stream),
-                        "hipMemcpy scan");
+        bool up;
+        if (b->ws) {
+            up = upload_scans_staged(b, images, n, raw, raw_off, raw_total);
+        } else {
+            up = hip_ok(ctx, hipMemsetAsync(raw, 0, raw_total + 1040, b->up), "hipMemset");
+            for (size_t i = 0; up && i < n; i++) {
+                if (!zj_image_supported(&images[i]) || images[i].scan_len == 0) continue;
+                up = hip_ok(ctx, hipMemcpyAsync(raw + raw_off[i], images[i].scan, images[i].scan_len, hipMemcpyHostToDevice, b->up), "hipMemcpy scan");
+            }
+            if (up) up = hip_ok(ctx, hipStreamSynchronize(b->up), "sync after upload");
         }
-        if (up) up = hip_ok(ctx, hipStreamSynchronize(ctx->stream), "sync after upload");
         if (!up) { zj_batch_destroy(b); return nullptr; }
     }
     std::vector<uint32_t> mark_first(n, ZJ_NONE), mark_count, mark_outfirst, mark_offs; // device-found restart offsets per image
@@ -257,22 +411,16 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
         return nullptr;
     }
 
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
     // MCUs per wavefront of the write pass: 32 (64 for 4:4:4) times a power of two up to 8, as long as the batch
     // still gives every CU several sets of wavefronts (measured: x8 is 7 % faster than x1 on a large batch).
     uint32_t k1w_mult = 1;
-    {
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        while (k1w_mult < 8u && mcus_total / (64u * k1w_mult) >= (uint64_t)cus * 12u * 4u) k1w_mult *= 2u;
-    }
+    while (k1w_mult < 8u && mcus_total / (64u * k1w_mult) >= (uint64_t)cus * 12u * 4u) k1w_mult *= 2u;
     // Strips per workgroup of the IDCT/colour kernel: 4, doubled up to 16 while the batch keeps every CU
     // supplied with workgroups (a strip is about 16 MCUs; measured: 16 is 4 % faster than 4 on a large batch).
     uint32_t k2_ns = ZJ_K2_NS;
-    {
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
-        while (k2_ns < 16u && mcus_total / 16u / (k2_ns * 2u) >= (uint64_t)cus * 16u) k2_ns *= 2u;
-    }
+    while (k2_ns < 16u && mcus_total / 16u / (k2_ns * 2u) >= (uint64_t)cus * 16u) k2_ns *= 2u;
     b->P.k2_ns = k2_ns;
     for (size_t i = 0; i < n; i++) {
         const zj_image &im = images[i];
@@ -377,7 +525,6 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
             if (k < nint) {
                 beg = offs[(size_t)k];
                 end = (k + 1 < nint) ? offs[(size_t)k + 1] - 2 : im.scan_len;
-                if (k + 1 == nseg) end = (k + 1 < nint) ? offs[(size_t)k + 1] - 2 : im.scan_len;
             }
             s.raw_begin = raw_off[i] + beg;
             s.raw_end = raw_off[i] + end;
@@ -449,7 +596,12 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
         b->coef_bytes += (uint64_t)d.nblocks * 128;
         b->rgb_bytes += (uint64_t)d.w * d.h * 3;
         b->pixels += (uint64_t)d.w * d.h;
-        if (nsub_total > 0xF0000000ull || nblk_total > 0xF0000000ull || nwin_total > 0xF0000000ull) { ctx->err = "batch too large for 32-bit indices"; delete b; return nullptr; }
+        if (nsub_total > 0xF0000000ull || nblk_total > 0xF0000000ull || nwin_total > 0xF0000000ull || ust_total > 0xF0000000ull) {
+            ctx->err = "batch too large for 32-bit indices";
+            ctx->err_code = ZJ_E_INVALID;
+            zj_batch_destroy(b);
+            return nullptr;
+        }
     }
 
     while (chunk_seg.size() % 4u) chunk_seg.push_back(ZJ_NONE); // whole workgroups
@@ -463,9 +615,6 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.ptile_seg = dev_upload(b, ptile_seg);
     P.tile_seg = dev_upload(b, tile_seg);
     P.dtile_seg = dev_upload(b, dtile_seg);
-    P.dtile_sum = dev_alloc<uint32_t>(b, dtile_seg.size() * 4, true);
-    P.tile_status = dev_alloc<uint64_t>(b, tile_seg.size() + (b->segs.size() + 1) / 2 + 1, true);
-    P.seg_ticket = P.tile_status ? reinterpret_cast<uint32_t *>(P.tile_status + tile_seg.size()) : nullptr;
     std::vector<uint32_t> strip_grp_all, strip_img_all;
     for (int c = 0; c < ZJ_K2_CLASSES; c++) {
         b->L.k2_first[c] = (uint32_t)strip_grp_all.size();
@@ -483,30 +632,59 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     P.canons = dev_upload(b, canons);
     P.qts = dev_upload(b, qts);
     P.raw = raw;
-    P.ust = dev_alloc<uint8_t>(b, ust_total + 1040, true);
-    P.seg_payload_bits = dev_alloc<uint32_t>(b, b->segs.size(), true);
-    P.seg_found = dev_alloc<uint32_t>(b, b->segs.size(), true);
-    P.winfo = dev_alloc<uint32_t>(b, nwin_total, true);
-    P.wbase = dev_alloc<uint32_t>(b, nwin_total, true);
-    P.bitmap = dev_alloc<uint8_t>(b, ust_total + 1040, true);
-    P.blockpos = dev_alloc<uint32_t>(b, nblk_total, true);
-    P.dcabs = dev_alloc<int16_t>(b, nblk_total, true);
-    P.dcbits = dev_alloc<uint8_t>(b, nblk_total, true);
-    P.qcoef = dev_alloc<int16_t>(b, nblk_total * 64, false);
     P.status = dev_alloc<uint32_t>(b, n, true);
     P.flags = dev_alloc<uint32_t>(b, 4, true);
     b->d_rgb = dev_alloc<uint8_t *>(b, n, true);
     b->d_stride = dev_alloc<size_t>(b, n, true);
+    ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.wluts && P.canons && P.qts &&
+         P.ptile_seg && P.tile_seg && P.dtile_seg && P.status && P.flags && b->d_rgb && b->d_stride;
+    if (ok && mode == ZJ_ALLOC_NONE) {
+        // the rest of the range is this call's scratch
+        const size_t used = align_up(b->plan_pool.off, 256);
+        b->scratch_pool = ZjPool{b->plan_pool.base + used, b->plan_pool.cap - used, 0};
+        b->plan_pool.cap = used;
+    }
+    if (ok) {
+        const int S = ZJ_MEM_SCRATCH;
+        P.dtile_sum = dev_alloc<uint32_t>(b, dtile_seg.size() * 4, true, S);
+        P.tile_status = dev_alloc<uint64_t>(b, tile_seg.size() + (b->segs.size() + 1) / 2 + 1, true, S);
+        P.seg_ticket = P.tile_status ? reinterpret_cast<uint32_t *>(P.tile_status + tile_seg.size()) : nullptr;
+        P.ust = dev_alloc<uint8_t>(b, ust_total + 1040, true, S);
+        P.seg_payload_bits = dev_alloc<uint32_t>(b, b->segs.size(), true, S);
+        P.seg_found = dev_alloc<uint32_t>(b, b->segs.size(), true, S);
+        P.winfo = dev_alloc<uint32_t>(b, nwin_total, true, S);
+        P.wbase = dev_alloc<uint32_t>(b, nwin_total, true, S);
+        P.bitmap = dev_alloc<uint8_t>(b, ust_total + 1040, true, S);
+        P.blockpos = dev_alloc<uint32_t>(b, nblk_total, true, S);
+        P.dcabs = dev_alloc<int16_t>(b, nblk_total, true, S);
+        P.dcbits = dev_alloc<uint8_t>(b, nblk_total, true, S);
+        P.qcoef = dev_alloc<int16_t>(b, nblk_total * 64, false, S);
+        ok = P.dtile_sum && P.tile_status && P.ust && P.seg_payload_bits && P.seg_found && P.winfo && P.wbase && P.bitmap && P.blockpos && P.dcabs &&
+             P.dcbits && P.qcoef;
+    }
     P.rgb = b->d_rgb;
     P.rgb_stride = b->d_stride;
     P.nchunks = (uint32_t)chunk_seg.size();
     P.nseg = (uint32_t)b->segs.size();
-    ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.wluts && P.canons && P.qts && raw && P.ust &&
-         P.seg_payload_bits && P.seg_found && P.winfo && P.wbase && P.bitmap && P.ptile_seg && P.tile_seg && P.tile_status && P.dtile_seg && P.dtile_sum && P.blockpos && P.dcabs && P.dcbits && P.qcoef && P.status &&
-         P.flags && b->d_rgb && b->d_stride;
-    if (ok) ok = hip_ok(ctx, hipHostMalloc((void **)&b->h_rgb, (n ? n : 1) * sizeof(uint8_t *), hipHostMallocDefault), "hipHostMalloc") &&
-                 hip_ok(ctx, hipHostMalloc((void **)&b->h_stride, (n ? n : 1) * sizeof(size_t), hipHostMallocDefault), "hipHostMalloc") &&
-                 hip_ok(ctx, hipHostMalloc((void **)&b->h_flags, 16, hipHostMallocDefault), "hipHostMalloc");
+    const size_t nn = n ? n : 1;
+    if (ok && b->pinned) {
+        ok = hip_ok(ctx, hipHostMalloc((void **)&b->h_rgb, nn * sizeof(uint8_t *), hipHostMallocDefault), "hipHostMalloc") &&
+             hip_ok(ctx, hipHostMalloc((void **)&b->h_stride, nn * sizeof(size_t), hipHostMallocDefault), "hipHostMalloc") &&
+             hip_ok(ctx, hipHostMalloc((void **)&b->h_flags, 16, hipHostMallocDefault), "hipHostMalloc") &&
+             hip_ok(ctx, hipEventCreateWithFlags(&b->tables_copied, hipEventDisableTiming), "hipEventCreate");
+        b->tables_ev_valid = ok;
+    } else if (ok) {
+        b->h_rgb = (uint8_t **)calloc(nn, sizeof(uint8_t *));
+        b->h_stride = (size_t *)calloc(nn, sizeof(size_t));
+        b->h_flags = (uint32_t *)calloc(4, sizeof(uint32_t));
+        if (!b->h_rgb || !b->h_stride || !b->h_flags) { ctx->err = "out of host memory"; ctx->err_code = ZJ_E_NOMEM; ok = false; }
+    }
+    if (ok && b->ws) {
+        // the decode stream waits for the uploads once, at the batch's first decode call
+        ok = hip_ok(ctx, hipEventCreateWithFlags(&b->ready, hipEventDisableTiming), "hipEventCreate");
+        b->ready_valid = ok;
+        if (ok) ok = hip_ok(ctx, hipEventRecord(b->ready, b->up), "event record");
+    }
     if (!ok) { zj_batch_destroy(b); return nullptr; }
     b->L.nseg = (uint32_t)b->segs.size();
     b->L.nchunks = P.nchunks;
@@ -517,7 +695,93 @@ extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t
     b->L.ndtiles = (uint32_t)dtile_seg.size();
     b->L.nstrips = (uint32_t)strip_grp_all.size();
     b->L.fix_iters = 1;
+    ctx->err_code = ZJ_OK;
     return b;
+}
+
+extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t n, uint32_t flags)
+{
+    return batch_create_impl(ctx, images, n, flags, ZJ_ALLOC_OWN, nullptr, 0, nullptr, 0);
+}
+
+// ---------------------------------------------------------------------------------- workspaces
+extern "C" int zj_workspace_estimate(const zj_image *images, size_t n, size_t *plan_bytes, size_t *scratch_bytes)
+{
+    if (!images && n) return ZJ_E_INVALID;
+    // upper bounds of what batch_create_impl takes, term by term (every allocation rounded up to 256 bytes)
+    uint64_t plan = 1040 + 64 * 256, scr = 2 * 1040 + 64 * 256;
+    for (size_t i = 0; i < n; i++) {
+        const zj_image &im = images[i];
+        plan += sizeof(ZjImgDev) + 4 + 16; // descriptor, status word, output pointer and pitch
+        if (!zj_image_supported(&im)) continue;
+        const uint64_t len = im.scan_len, M = zj_image_mcus(&im), B = align_up((size_t)zj_image_blocks(&im), 256);
+        const uint64_t S = im.restart_interval ? (M + im.restart_interval - 1) / im.restart_interval : 1;
+        const uint64_t win = len / 32 + 64 * S + 512;  // at most two windows per 512 bits (rounding per lane), whole chunks
+        const uint64_t chunks = win / 64 + S + 8;
+        const uint64_t utiles = len / ZJ_UNSTUFF_TILE + 2 * S, ptiles = win / 256 + S, dtiles = M / 256 + S;
+        const uint64_t mtiles = len / ZJ_MARK_TILE + 1;
+        plan += align_up((size_t)len, 16) + 16 + S * sizeof(ZjSegDev) + 4 * (chunks + B / 256 + (M / 128 + 1) + ptiles + utiles + dtiles) + 8 * (M / 16 + 2);
+        plan += 2 * ZJ_SET_ENTRIES * 2 + 4 * sizeof(ZjCanon) + 3 * 64 * 2;  // a table set and quantisation tables of its own
+        plan += sizeof(ZjMarkImg) + 8 * mtiles + 4 + 4 * (S + 1);           // restart-marker search
+        scr += 16 * dtiles + 8 * (utiles + S) + 2 * (len + 112 * S) + 8 * S + 8 * win + 7 * B + 128 * B;
+    }
+    if (plan_bytes) *plan_bytes = (size_t)(plan + plan / 64);
+    if (scratch_bytes) *scratch_bytes = (size_t)(scr + scr / 64);
+    return ZJ_OK;
+}
+
+extern "C" void zj_workspace_destroy(zj_workspace *ws)
+{
+    if (!ws) return;
+    (void)hipSetDevice(ws->ctx->device);
+    if (ws->copy_stream) { (void)hipStreamSynchronize(ws->copy_stream); (void)hipStreamDestroy(ws->copy_stream); }
+    (void)hipStreamSynchronize(ws->ctx->stream);
+    for (int k = 0; k < 2; k++) {
+        if (ws->stage[k]) (void)hipHostFree(ws->stage[k]);
+        if (ws->stage_free[k]) (void)hipEventDestroy(ws->stage_free[k]);
+    }
+    if (ws->scratch) (void)hipFree(ws->scratch);
+    if (ws->plan) (void)hipFree(ws->plan);
+    delete ws;
+}
+
+extern "C" zj_workspace *zj_workspace_create(zj_ctx *ctx, size_t scratch_bytes, size_t plan_bytes, uint32_t nslots)
+{
+    if (!ctx) return nullptr;
+    ctx->err_code = ZJ_E_INVALID;
+    if (nslots == 0 || scratch_bytes == 0 || plan_bytes == 0) { ctx->err = "workspace sizes and slot count must be positive"; return nullptr; }
+    if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return nullptr;
+    zj_workspace *ws = new zj_workspace();
+    memset(ws, 0, sizeof *ws);
+    ws->ctx = ctx;
+    ws->scratch_bytes = align_up(scratch_bytes, 256);
+    ws->plan_bytes = align_up(plan_bytes, 256);
+    ws->nslots = nslots;
+    ws->stage_bytes = std::min<size_t>(32u << 20, align_up(plan_bytes, 4096));
+    bool ok = hip_ok(ctx, hipMalloc((void **)&ws->scratch, ws->scratch_bytes), "hipMalloc workspace scratch") &&
+              hip_ok(ctx, hipMalloc((void **)&ws->plan, ws->plan_bytes * nslots), "hipMalloc workspace plan slots") &&
+              hip_ok(ctx, hipStreamCreateWithFlags(&ws->copy_stream, hipStreamNonBlocking), "hipStreamCreate");
+    for (int k = 0; ok && k < 2; k++)
+        ok = hip_ok(ctx, hipHostMalloc((void **)&ws->stage[k], ws->stage_bytes, hipHostMallocDefault), "hipHostMalloc staging") &&
+             hip_ok(ctx, hipEventCreateWithFlags(&ws->stage_free[k], hipEventDisableTiming), "hipEventCreate");
+    if (!ok) { zj_workspace_destroy(ws); return nullptr; }
+    ctx->err_code = ZJ_OK;
+    return ws;
+}
+
+extern "C" zj_batch *zj_batch_create_in(zj_workspace *ws, uint32_t slot, const zj_image *images, size_t n, uint32_t flags)
+{
+    if (!ws) return nullptr;
+    if (slot >= ws->nslots) { ws->ctx->err = "no such plan slot"; ws->ctx->err_code = ZJ_E_INVALID; return nullptr; }
+    return batch_create_impl(ws->ctx, images, n, flags, ZJ_ALLOC_WORKSPACE, ws, slot, nullptr, 0);
+}
+
+extern "C" int zj_batch_memory(zj_batch *b, size_t *plan_bytes, size_t *scratch_bytes)
+{
+    if (!b) return ZJ_E_INVALID;
+    if (plan_bytes) *plan_bytes = b->plan_pooled ? b->plan_pool.off : 0;
+    if (scratch_bytes) *scratch_bytes = b->scratch_pooled ? b->scratch_pool.off : 0;
+    return ZJ_OK;
 }
 
 extern "C" int zj_batch_decode(zj_batch *b, uint8_t *const *rgb, const size_t *stride)
@@ -526,15 +790,34 @@ extern "C" int zj_batch_decode(zj_batch *b, uint8_t *const *rgb, const size_t *s
     zj_ctx *c = b->ctx;
     if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return ZJ_E_DEVICE;
     hipStream_t st = c->stream;
+    for (size_t i = 0; i < b->n; i++) {
+        if (rgb && rgb[i] && !b->unsupported[i] && stride && stride[i] && stride[i] < (size_t)b->imgs[i].w * 3u) {
+            c->err = "output pitch is smaller than 3 * width";
+            return ZJ_E_INVALID;
+        }
+    }
+    // the copies of the previous call may still be reading the staging tables
+    if (b->tables_ev_pending) {
+        if (!hip_ok(c, hipEventSynchronize(b->tables_copied), "event sync")) return ZJ_E_DEVICE;
+        b->tables_ev_pending = false;
+    }
     bool any_rgb = false;
     for (size_t i = 0; i < b->n; i++) {
         b->h_rgb[i] = (rgb && !b->unsupported[i]) ? rgb[i] : nullptr;
         b->h_stride[i] = stride ? stride[i] : 0;
         any_rgb = any_rgb || b->h_rgb[i];
     }
+    if (b->ready_valid && !b->ready_waited) {
+        if (!hip_ok(c, hipStreamWaitEvent(st, b->ready, 0), "stream wait")) return ZJ_E_DEVICE;
+        b->ready_waited = true;
+    }
     if (b->n) {
         if (!hip_ok(c, hipMemcpyAsync(b->d_rgb, b->h_rgb, b->n * sizeof(uint8_t *), hipMemcpyHostToDevice, st), "H2D rgb table")) return ZJ_E_DEVICE;
         if (!hip_ok(c, hipMemcpyAsync(b->d_stride, b->h_stride, b->n * sizeof(size_t), hipMemcpyHostToDevice, st), "H2D stride table")) return ZJ_E_DEVICE;
+        if (b->tables_ev_valid) {
+            if (!hip_ok(c, hipEventRecord(b->tables_copied, st), "event record")) return ZJ_E_DEVICE;
+            b->tables_ev_pending = true;
+        }
         if (!hip_ok(c, hipMemsetAsync(b->P.status, 0, b->n * sizeof(uint32_t), st), "memset status")) return ZJ_E_DEVICE;
     }
     if (b->L.nchunks == 0) { b->decoded = true; return ZJ_OK; }
@@ -568,8 +851,14 @@ extern "C" int zj_batch_finish(zj_batch *b, uint32_t *status)
         if (b->h_flags[0] || b->h_flags[1]) {
             // Subsequence records did not converge in the fixed number of fix-up passes: iterate to a
             // fixed point (each pass completes at least one more chunk), then redo everything behind.
+            b->slow_path_calls++;
+            if (b->scratch_pooled) {
+                // another batch may have used the shared scratch since: start over from the stuffed scans
+                zj_launch_stage1(b->P, b->L, st, nullptr);
+                if (!hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
+            }
             for (uint32_t it = 0; it <= b->L.nchunks; it++) {
-                if (!hip_ok(c, hipMemsetAsync(b->P.flags, 0, 16, st), "memset flags")) return ZJ_E_DEVICE;
+                if (!hip_ok(c, hipMemsetAsync(b->P.flags, 0, 8, st), "memset flags")) return ZJ_E_DEVICE;
                 zj_launch_fix_only(b->P, b->L, st);
                 if (!hip_ok(c, hipMemcpyAsync(b->h_flags, b->P.flags, 16, hipMemcpyDeviceToHost, st), "D2H flags")) return ZJ_E_DEVICE;
                 if (!hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
@@ -592,6 +881,20 @@ extern "C" int zj_batch_finish(zj_batch *b, uint32_t *status)
         for (size_t i = 0; i < b->n; i++)
             if (b->unsupported[i]) status[i] = ZJ_ST_UNSUPPORTED;
     }
+    return ZJ_OK;
+}
+
+extern "C" int zj_batch_counters(zj_batch *b, uint32_t *counters)
+{
+    if (!b || !counters) return ZJ_E_INVALID;
+    zj_ctx *c = b->ctx;
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return ZJ_E_DEVICE;
+    if (!hip_ok(c, hipStreamSynchronize(c->stream), "stream sync")) return ZJ_E_DEVICE;
+    uint32_t f[4] = {0, 0, 0, 0};
+    if (b->P.flags && !hip_ok(c, hipMemcpy(f, b->P.flags, 16, hipMemcpyDeviceToHost), "D2H flags")) return ZJ_E_DEVICE;
+    counters[0] = f[2];
+    counters[1] = f[3];
+    counters[2] = b->slow_path_calls;
     return ZJ_OK;
 }
 
@@ -668,7 +971,7 @@ extern "C" int zj_decode_batch(zj_ctx *ctx, const zj_image *imgs, size_t n, cons
 {
     if (!ctx || (!imgs && n) || (!outs && n)) return ZJ_E_INVALID;
     zj_batch *b = zj_batch_create(ctx, imgs, n, 0);
-    if (!b) return ZJ_E_DEVICE;
+    if (!b) return ctx->err_code ? ctx->err_code : ZJ_E_DEVICE;
     std::vector<uint8_t *> rgb(n, nullptr);
     std::vector<size_t> stride(n, 0);
     std::vector<void *> tmp;
@@ -679,6 +982,7 @@ extern "C" int zj_decode_batch(zj_ctx *ctx, const zj_image *imgs, size_t n, cons
         else {
             void *p = nullptr;
             const size_t row = align_up((size_t)imgs[i].width * 3, 16);
+            if (outs[i].rgb_stride && outs[i].rgb_stride < (size_t)imgs[i].width * 3) { ctx->err = "output pitch is smaller than 3 * width"; rc = ZJ_E_INVALID; break; }
             if (!hip_ok(ctx, hipMalloc(&p, row * imgs[i].height + 16), "hipMalloc rgb")) { rc = ZJ_E_NOMEM; break; }
             tmp.push_back(p);
             rgb[i] = (uint8_t *)p;
@@ -700,3 +1004,4 @@ extern "C" int zj_decode_batch(zj_ctx *ctx, const zj_image *imgs, size_t n, cons
     zj_batch_destroy(b);
     return rc;
 }
+

@@ -400,6 +400,12 @@ __global__ __launch_bounds__(ZJ_K0_THREADS) void zj_k0_unstuff(ZjParams P)
                 if (b0 + k >= shift && b0 + k < endpos) out[b0 + k] = buf[src + k];
         }
     }
+    // The segment's last tile clears the reserved bytes behind the payload: the readers run up to 96 bytes
+    // past it and must find zeros there (src/bitstream.rs:80-84), whatever the arena held before.
+    if (tile + 1u == sg.first_tile + sg.ntiles) {
+        uint8_t *seg_out = P.ust + sg.out_off;
+        for (uint32_t i = prefix + total + tid; i < sg.out_cap; i += ZJ_K0_THREADS) seg_out[i] = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------- k1a: sync
@@ -444,9 +450,9 @@ __device__ __forceinline__ void zj_k1a_body(const ZjParams &P, const ZjImgDev &i
     {
         const uint32_t end = act0 ? sub_end(jl, SB, pay) : 0u;
         for (uint32_t c = 0; c < NC; c++) {
-            const bool run = act0 && st.p < end;
-            if (!__any(run)) break;
             const uint32_t w = jl * NC + c;
+            const bool run = act0 && w * ZJ_WIN_BITS < end; // every window that begins inside the payload gets its record and bitmap words
+            if (!__any(run)) break;
             const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
             if (run) rec[c * 64u + lane] = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
         }
@@ -459,9 +465,9 @@ __device__ __forceinline__ void zj_k1a_body(const ZjParams &P, const ZjImgDev &i
         if (!__any(act)) break;
         const uint32_t end = act ? sub_end(q, SB, pay) : 0u;
         for (uint32_t c = 0; c < NC; c++) {
-            const bool run = act && st.p < end;
-            if (!__any(run)) break;
             const uint32_t w = q * NC + c;
+            const bool run = act && w * ZJ_WIN_BITS < end;
+            if (!__any(run)) break;
             const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
             if (run) {
                 const uint32_t nw = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
@@ -511,9 +517,9 @@ __device__ __forceinline__ void zj_k1a_body_packed(const ZjParams &P, const ZjIm
     {
         const uint32_t end = act0 ? sub_stop(jl) : 0u;
         for (uint32_t c = 0;; c++) {
-            const bool run = act0 && c < NC && st.p < end;
-            if (!__any(run)) break;
             const uint32_t w = jl * NC + c;
+            const bool run = act0 && c < NC && w * ZJ_WIN_BITS < end;
+            if (!__any(run)) break;
             const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
             if (run) rec[c * G + jl] = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
         }
@@ -526,9 +532,9 @@ __device__ __forceinline__ void zj_k1a_body_packed(const ZjParams &P, const ZjIm
         if (!__any(act)) break;
         const uint32_t end = act ? sub_stop(tgt) : 0u;
         for (uint32_t c = 0;; c++) {
-            const bool run = act && c < NC && st.p < end;
-            if (!__any(run)) break;
             const uint32_t w = tgt * NC + c;
+            const bool run = act && c < NC && w * ZJ_WIN_BITS < end;
+            if (!__any(run)) break;
             const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
             if (run) {
                 const uint32_t nw = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
@@ -635,8 +641,8 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
         if (!sub_active(sg, q, SB, pay)) return;
         const uint32_t end = sub_end(q, SB, pay);
         for (uint32_t c = 0; c < NC; c++) {
-            if (st.p >= end) break;
             const uint32_t w = q * NC + c;
+            if (w * ZJ_WIN_BITS >= end) break;
             const uint32_t wend = (w + 1u) * ZJ_WIN_BITS;
 #pragma unroll
             for (int i = 0; i < ZJ_WIN_WORDS; i++) em.col[i * 64] = 0;
@@ -658,6 +664,7 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
         }
     }
     atomicOr(&P.flags[0], 1u); // ran through the whole chunk: the next one may have started from a stale state
+    atomicAdd(&P.flags[2], 1u);  // the same, counted over the batch's life (never cleared by a decode call)
 }
 
 // ---------------------------------------------------------------------------------- k1s: scan
@@ -1069,7 +1076,7 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
             if (p > cur.pay) st |= 4u;                                 // ZJ_ST_TRUNCATED
             // a cleanly decoded block ends where the next one begins; if it does not, the position
             // list does not describe the sequential decode
-            if (st == 0u && pnext != 0xFFFFFFFFu && pnext != p) atomicOr(&P.flags[1], 1u);
+            if (st == 0u && pnext != 0xFFFFFFFFu && pnext != p) { atomicOr(&P.flags[1], 1u); atomicAdd(&P.flags[3], 1u); }
             status |= st;
         }
         cur = nxt; nxt = nn;
@@ -1611,7 +1618,7 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
 {
     int e = 0;
     if (ev) hipEventRecord(ev[e++], st);
-    hipMemsetAsync(P.flags, 0, 16, st);
+    hipMemsetAsync(P.flags, 0, 8, st); // words 2 and 3 count over the batch's life
     hipMemsetAsync(P.tile_status, 0, (size_t)L.ntiles * sizeof(uint64_t) + (size_t)L.nseg * sizeof(uint32_t), st); // look-back words and the tickets behind them
     if (L.ntiles) hipLaunchKernelGGL(zj_k0_unstuff, dim3(L.ntiles), dim3(ZJ_K0_THREADS), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);

@@ -129,19 +129,63 @@ class Context:
             pass
 
 
-class Batch:
-    """A planned batch of parsed images, resident on the GPU (zj_batch_create)."""
+def image_array(images):
+    """ctypes array of zj_image for a list of ParsedImage / BandImage."""
+    arr = (B.zj_image * max(len(images), 1))()
+    for i, im in enumerate(images):
+        arr[i] = im.image
+    return arr
 
-    def __init__(self, ctx: Context, images, subseq_bits=0):
+
+class Workspace:
+    """Device memory shared by batches that decode one after the other (zj_workspace_create): one scratch
+    range (coefficient arena and all intermediates) and `nslots` plan ranges.  Sizes in bytes; use
+    Workspace.estimate(images) for the upper bounds of one batch."""
+
+    def __init__(self, ctx: Context, scratch_bytes, plan_bytes, nslots=2):
+        self.ctx = ctx
+        self.nslots = nslots
+        self.h = B.lib().zj_workspace_create(ctx.h, scratch_bytes, plan_bytes, nslots)
+        if not self.h:
+            raise DecodeError("device", "zj_workspace_create failed: " + ctx.last_error())
+
+    @staticmethod
+    def estimate(images):
+        plan, scratch = C.c_size_t(), C.c_size_t()
+        arr = image_array(list(images))
+        rc = B.lib().zj_workspace_estimate(arr, len(images), C.byref(plan), C.byref(scratch))
+        if rc != B.ZJ_OK:
+            raise DecodeError("format", "zj_workspace_estimate failed")
+        return plan.value, scratch.value
+
+    def close(self):
+        if self.h:
+            B.lib().zj_workspace_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """A planned batch of parsed images, resident on the GPU (zj_batch_create, or zj_batch_create_in
+    when a workspace and one of its plan slots are given)."""
+
+    def __init__(self, ctx: Context, images, subseq_bits=0, workspace=None, slot=0):
         self.ctx = ctx
         self.images = list(images)
         n = len(self.images)
         self.n = n
-        arr = (B.zj_image * max(n, 1))()
-        for i, im in enumerate(self.images):
-            arr[i] = im.image
+        arr = image_array(self.images)
         self._arr = arr
-        self.h = B.lib().zj_batch_create(ctx.h, arr, n, subseq_bits)
+        self.workspace = workspace
+        if workspace is None:
+            self.h = B.lib().zj_batch_create(ctx.h, arr, n, subseq_bits)
+        else:
+            self.h = B.lib().zj_batch_create_in(workspace.h, slot, arr, n, subseq_bits)
         if not self.h:
             raise DecodeError("device", "zj_batch_create failed: " + ctx.last_error())
         self._rgb = None
@@ -163,6 +207,7 @@ class Batch:
         if rgb_tensors is not None:
             for i, t in enumerate(rgb_tensors):
                 if t is not None:
+                    check_output_tensor(t, self.images[i], self.ctx.device)
                     ptrs[i] = t.data_ptr()
                     strides[i] = t.stride(0)
         self._rgb = rgb_tensors
@@ -204,6 +249,21 @@ class Batch:
         B.lib().zj_batch_bytes(self.h, *[C.byref(x) for x in v])
         return {"scan": v[0].value, "coef": v[1].value, "rgb": v[2].value, "pixels": v[3].value}
 
+    def counters(self):
+        """(fix-up lanes that ran through a whole chunk, blocks that ended off their successor's position,
+        finish calls that ran the exhaustive fix-up loop) over the batch's life; all 0 on the fast path."""
+        c = (C.c_uint32 * 3)()
+        rc = B.lib().zj_batch_counters(self.h, c)
+        if rc != B.ZJ_OK:
+            raise DecodeError("device", self.ctx.last_error())
+        return int(c[0]), int(c[1]), int(c[2])
+
+    def memory(self):
+        """(plan bytes, scratch bytes) taken from a workspace; (0, 0) for a batch that owns its memory."""
+        p, s_ = C.c_size_t(), C.c_size_t()
+        B.lib().zj_batch_memory(self.h, C.byref(p), C.byref(s_))
+        return p.value, s_.value
+
     def segments(self, i):
         """(begin, end) byte offsets inside image i's scan of the entropy-coded segments it was cut into."""
         n = B.lib().zj_batch_segments(self.h, i, None, 0)
@@ -221,6 +281,19 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+def check_output_tensor(t, im, device):
+    """A pixel output must be a 2-D uint8 tensor on the context's GPU with unit inner stride, at least
+    `height` rows and a row pitch of at least 3 * width bytes: the kernels write exactly that region."""
+    if str(t.dtype) != "torch.uint8":
+        raise DecodeError("device", f"output tensor must be uint8, got {t.dtype}")
+    if t.dim() != 2 or not t.is_cuda or t.device.index != device:
+        raise DecodeError("device", f"output tensor must be 2-D on cuda:{device}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise DecodeError("device", "output tensor rows must be contiguous")
+    if t.shape[0] < im.height or t.shape[1] < 3 * im.width or (im.height > 1 and t.stride(0) < 3 * im.width):
+        raise DecodeError("device", f"output tensor {tuple(t.shape)} (pitch {t.stride(0)}) is too small for {im.width}x{im.height} RGB")
 
 
 def decode_images(ctx: Context, images, subseq_bits=0, want_coef=False):

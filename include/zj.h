@@ -220,6 +220,19 @@ int zj_batch_bytes(zj_batch *b, uint64_t *scan_bytes, uint64_t *coef_bytes, uint
  * plan + decode + finish + copy-out + destroy.  outs[i].mem selects host or device outputs. */
 int zj_decode_batch(zj_ctx *ctx, const zj_image *imgs, size_t n, const zj_output *outs, uint32_t *status);
 
+/* zj_decode_batch for callers that cannot allocate device memory -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same work as
+ * zj_decode_batch with ZJ_MEM_DEVICE pixel outputs (rgb[i] device pointers, NULL = skip the pixels of
+ * image i; stride[i] in bytes, NULL or 0 = 3 * width), but every device buffer the decode needs -- uploaded
+ * scans, tables, unstuffed streams, bitmaps, window records, block positions, quantised coefficients --
+ * lies in one fixed array of ZJ_NOALLOC_MAX_BYTES that the library holds on each GPU it runs on until the
+ * process ends.  The call makes no hipMalloc / hipFree / hipHostMalloc and creates no stream or event.
+ * Inputs that need more than the array return ZJ_E_NOMEM (zj_last_error names the limit); as a guide, one
+ * 1920x1080 4:4:4 image takes about 19 MB, one 3840x2160 4:2:0 image about 40 MB.  All calls on one GPU
+ * share the array: calls that overlap in time on one GPU (from several contexts or threads) race. */
+#define ZJ_NOALLOC_MAX_BYTES (64u << 20)
+int zj_decode_batch_noalloc(zj_ctx *ctx, const zj_image *imgs, size_t n, uint8_t *const *rgb, const size_t *stride, uint32_t *status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ ZJ_MEM_HOST, ZJ_MEM_DEVICE = 0, 1
 ZJ_FLAG_NO_SECOND_LEVEL = 0x1000000
 ZJ_FLAG_HOST_MARKER_SCAN = 0x2000000
 ZJ_NUM_KERNELS = 9
+ZJ_NOALLOC_MAX_BYTES = 64 << 20
 
 
 class zj_huff(C.Structure):
@@ -59,6 +60,7 @@ _EXPORTS = [
     "zj_decode_batch",
     "zj_workspace_estimate", "zj_workspace_create", "zj_workspace_destroy", "zj_batch_create_in", "zj_batch_memory",
     "zj_batch_counters",
+    "zj_decode_batch_noalloc",
 ]
 
 
@@ -106,6 +108,7 @@ def lib():
     L.zj_batch_create_in.argtypes = [vp, C.c_uint32, C.POINTER(zj_image), sz, C.c_uint32]; L.zj_batch_create_in.restype = vp
     L.zj_batch_memory.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]; L.zj_batch_memory.restype = C.c_int
     L.zj_batch_counters.argtypes = [vp, u32p]; L.zj_batch_counters.restype = C.c_int
+    L.zj_decode_batch_noalloc.argtypes = [vp, C.POINTER(zj_image), sz, C.POINTER(vp), C.POINTER(sz), u32p]; L.zj_decode_batch_noalloc.restype = C.c_int
     _lib = L
     return L
 

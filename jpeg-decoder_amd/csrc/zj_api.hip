@@ -7,12 +7,14 @@
 //   * zj_batch_create_in       plan memory from one slot of a workspace, scratch from the workspace's
 //                              shared scratch range: no allocation per batch, the coefficient arena and all
 //                              intermediates are reused by the next batch
+//   * zj_decode_batch_noalloc  plan and scratch from a file-scope __device__ array: no allocation at all
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -96,6 +98,28 @@ static bool hip_ok(zj_ctx *c, hipError_t e, const char *what)
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---------------------------------------------------------------------------------- the no-allocation scratch
+// Plan and scratch memory of zj_decode_batch_noalloc.  The array's name is a host-side handle, not a device
+// address: every use on the host goes through the pointer hipGetSymbolAddress returned for the device in
+// question (each GPU holds its own copy of the array at its own address).
+static __device__ __align__(256) uint8_t zj_noalloc_scratch[ZJ_NOALLOC_MAX_BYTES];
+#define ZJ_MAX_DEVICES 64
+static uint8_t *g_noalloc_ptr[ZJ_MAX_DEVICES];
+static std::mutex g_noalloc_mutex;
+
+// Address of the array on `device`, which must be the current device; looked up once per device.
+static uint8_t *noalloc_ptr(zj_ctx *c, int device)
+{
+    if (device < 0 || device >= ZJ_MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (!g_noalloc_ptr[device]) {
+        void *p = nullptr;
+        if (!hip_ok(c, hipGetSymbolAddress(&p, HIP_SYMBOL(zj_noalloc_scratch)), "hipGetSymbolAddress")) return nullptr;
+        g_noalloc_ptr[device] = (uint8_t *)p;
+    }
+    return g_noalloc_ptr[device];
+}
+
 extern "C" int zj_device_count(void)
 {
     int n = 0;
@@ -114,6 +138,13 @@ extern "C" zj_ctx *zj_create(int device, void *stream)
     c->own_stream = (stream == nullptr);
     if (stream) c->stream = (hipStream_t)stream;
     else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+    // the no-allocation entry point's memory on this device: its address is looked up here, at set-up, so
+    // that the entry point itself only reads a table
+    if (!noalloc_ptr(c, device)) {
+        if (c->own_stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return nullptr;
+    }
     return c;
 }
 
@@ -309,7 +340,7 @@ static bool upload_scans_staged(zj_batch *b, const zj_image *images, size_t n, u
 
 enum { ZJ_ALLOC_OWN = 0, ZJ_ALLOC_WORKSPACE, ZJ_ALLOC_NONE };
 
-// The planner behind zj_batch_create and zj_batch_create_in.
+// The planner behind zj_batch_create, zj_batch_create_in and zj_decode_batch_noalloc.
 // ZJ_ALLOC_NONE: plan and scratch memory both come out of the range [fixed_base, fixed_base + fixed_cap).
 static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n, uint32_t flags, int mode, zj_workspace *ws, uint32_t slot,
                                    uint8_t *fixed_base, size_t fixed_cap)
@@ -1005,3 +1036,23 @@ extern "C" int zj_decode_batch(zj_ctx *ctx, const zj_image *imgs, size_t n, cons
     return rc;
 }
 
+// ---------------------------------------------------------------------------------- no-allocation entry point
+// zj_decode_batch for callers that cannot allocate: device outputs only, plan and scratch memory inside
+// zj_noalloc_scratch.  Calls no hipMalloc / hipFree / hipHostMalloc and creates no stream or event; the host
+// side uses the C heap for the planner's lists.
+extern "C" int zj_decode_batch_noalloc(zj_ctx *ctx, const zj_image *imgs, size_t n, uint8_t *const *rgb, const size_t *stride, uint32_t *status)
+{
+    if (!ctx || (!imgs && n)) return ZJ_E_INVALID;
+    if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return ZJ_E_DEVICE;
+    uint8_t *base = noalloc_ptr(ctx, ctx->device);
+    if (!base) return ZJ_E_DEVICE;
+    zj_batch *b = batch_create_impl(ctx, imgs, n, 0, ZJ_ALLOC_NONE, nullptr, 0, base, ZJ_NOALLOC_MAX_BYTES);
+    if (!b) {
+        if (ctx->err_code == ZJ_E_NOMEM) ctx->err = "input exceeds the no-allocation entry point's fixed scratch of " + std::to_string(ZJ_NOALLOC_MAX_BYTES) + " bytes: " + ctx->err;
+        return ctx->err_code ? ctx->err_code : ZJ_E_DEVICE;
+    }
+    int rc = zj_batch_decode(b, rgb, stride);
+    if (rc == ZJ_OK) rc = zj_batch_finish(b, status);
+    zj_batch_destroy(b); // frees host lists only: the batch owns no device memory
+    return rc;
+}

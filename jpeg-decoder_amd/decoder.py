@@ -296,6 +296,24 @@ def check_output_tensor(t, im, device):
         raise DecodeError("device", f"output tensor {tuple(t.shape)} (pitch {t.stride(0)}) is too small for {im.width}x{im.height} RGB")
 
 
+def decode_noalloc(ctx: Context, images, rgb_tensors):
+    """zj_decode_batch_noalloc: one call, device outputs, no device allocation.  Returns the status words."""
+    n = len(images)
+    arr = image_array(list(images))
+    ptrs = (C.c_void_p * max(n, 1))()
+    strides = (C.c_size_t * max(n, 1))()
+    for i, t in enumerate(rgb_tensors):
+        if t is not None:
+            check_output_tensor(t, images[i], ctx.device)
+            ptrs[i] = t.data_ptr()
+            strides[i] = t.stride(0)
+    st = np.zeros(max(n, 1), np.uint32)
+    rc = B.lib().zj_decode_batch_noalloc(ctx.h, arr, n, ptrs, strides, st.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if rc != B.ZJ_OK:
+        raise DecodeError("nomem" if rc == B.ZJ_E_NOMEM else "device", ctx.last_error())
+    return st[:n]
+
+
 def decode_images(ctx: Context, images, subseq_bits=0, want_coef=False):
     """Decode parsed images; returns (list of HxWx3 uint8 numpy arrays, status array[, coefficient list])."""
     b = Batch(ctx, images, subseq_bits)

@@ -1156,6 +1156,48 @@ __device__ __forceinline__ uint32_t zj_pack_u8(float v, uint32_t pos, uint32_t o
     return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_truncf(v), pos, old);
 }
 
+// Twenty-four values to twenty-four bytes (six words, byte j of the run from v[j]) with the same cast, without
+// the v_trunc_f32 in front of every conversion: v_cvt_pk_u8_f32 rounds by the wavefront's f32 rounding mode
+// (checked on the hardware, tools/micro/cvt_pk_u8_rtz.hip), so the mode is switched to round-toward-zero for
+// the conversions and back.  One asm statement, so that nothing else can be scheduled between the two
+// switches: every other f32 operation of the kernel must run in round-to-nearest-even.
+__device__ __forceinline__ void zj_pack24_u8(const float (&v)[24], uint32_t *w)
+{
+    uint32_t w0, w1, w2, w3, w4, w5;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "s_nop 1\n\t"
+                 "v_cvt_pk_u8_f32 %0, %6, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %10, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %2, %14, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %3, %18, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %4, %22, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %5, %26, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %7, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %11, 1, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %15, 1, %2\n\t"
+                 "v_cvt_pk_u8_f32 %3, %19, 1, %3\n\t"
+                 "v_cvt_pk_u8_f32 %4, %23, 1, %4\n\t"
+                 "v_cvt_pk_u8_f32 %5, %27, 1, %5\n\t"
+                 "v_cvt_pk_u8_f32 %0, %8, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %12, 2, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %16, 2, %2\n\t"
+                 "v_cvt_pk_u8_f32 %3, %20, 2, %3\n\t"
+                 "v_cvt_pk_u8_f32 %4, %24, 2, %4\n\t"
+                 "v_cvt_pk_u8_f32 %5, %28, 2, %5\n\t"
+                 "v_cvt_pk_u8_f32 %0, %9, 3, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %13, 3, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %17, 3, %2\n\t"
+                 "v_cvt_pk_u8_f32 %3, %21, 3, %3\n\t"
+                 "v_cvt_pk_u8_f32 %4, %25, 3, %4\n\t"
+                 "v_cvt_pk_u8_f32 %5, %29, 3, %5\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(w4), "=&v"(w5)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
+                   "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(v[16]), "v"(v[17]), "v"(v[18]),
+                   "v"(v[19]), "v"(v[20]), "v"(v[21]), "v"(v[22]), "v"(v[23]));
+    w[0] = w0; w[1] = w1; w[2] = w2; w[3] = w3; w[4] = w4; w[5] = w5;
+}
+
 // Byte offset (4 * natural index) of the zig-zag positions 8*part .. 8*part+7, one byte each: the
 // inverse of the table at src/decoder.rs:114-124, i.e. the zig-zag scan order of T.81 Figure A.6.
 #define ZJ_NAT8(a, b, c, d, e, f, g, h)                                                                            \
@@ -1320,6 +1362,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
 #pragma unroll
                     for (int k = 0; k < 8; k++) in[k] = yp[k];
                     zj_idct_1d(in, yv);
+                    float rgbv[24]; // the eight pixels of this block row, r g b each
 #pragma unroll
                     for (int x = 0; x < 8; x += 2) {
                         const int cx0 = (u * 8 + x) / HS, cx1 = (u * 8 + x + 1) / HS;
@@ -1327,14 +1370,10 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
                         const zj_f32x2 r2 = zj_f32x2{pr[cx0], pr[cx1]} + y2;
                         const zj_f32x2 g2 = zj_f32x2{pg[cx0], pg[cx1]} + y2;
                         const zj_f32x2 b2 = zj_f32x2{pb[cx0], pb[cx1]} + y2;
-                        const int o = (u * 8 + x) * 3; // byte offset of the pair inside the lane's run
-                        px[it][(o + 0) >> 2] = zj_pack_u8(r2.x, (o + 0) & 3, px[it][(o + 0) >> 2]);
-                        px[it][(o + 1) >> 2] = zj_pack_u8(g2.x, (o + 1) & 3, px[it][(o + 1) >> 2]);
-                        px[it][(o + 2) >> 2] = zj_pack_u8(b2.x, (o + 2) & 3, px[it][(o + 2) >> 2]);
-                        px[it][(o + 3) >> 2] = zj_pack_u8(r2.y, (o + 3) & 3, px[it][(o + 3) >> 2]);
-                        px[it][(o + 4) >> 2] = zj_pack_u8(g2.y, (o + 4) & 3, px[it][(o + 4) >> 2]);
-                        px[it][(o + 5) >> 2] = zj_pack_u8(b2.y, (o + 5) & 3, px[it][(o + 5) >> 2]);
+                        rgbv[3 * x + 0] = r2.x; rgbv[3 * x + 1] = g2.x; rgbv[3 * x + 2] = b2.x;
+                        rgbv[3 * x + 3] = r2.y; rgbv[3 * x + 4] = g2.y; rgbv[3 * x + 5] = b2.y;
                     }
+                    zj_pack24_u8(rgbv, &px[it][u * 6]); // bytes u*24 .. u*24+23 of the lane's run
                 }
             }
         }

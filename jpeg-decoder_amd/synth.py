@@ -7,6 +7,8 @@ LIB_PATH = os.path.join(_HERE, "synth", "libzjsynth.so")
 _lib = None
 
 NATURAL, SMOOTH, NOISE = 0, 1, 2
+# added to the content class: which table ids the luma component uses (the chroma components get the other id)
+LUMA_DC_ID1, LUMA_AC_ID1, LUMA_QT_ID1 = 0x100, 0x200, 0x400
 
 
 def lib():

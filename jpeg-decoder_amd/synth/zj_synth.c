@@ -230,12 +230,18 @@ static void fetch_block(const float *plane, int pw, int ph, int bx, int by, int 
  * Encode one synthetic image.  hs, vs: luma sampling factors (1 or 2); chroma is 1x1.
  * hs = vs = 0: a one-component (grayscale) file that codes the luma plane of the same content.
  * content class: 0 natural, 1 smooth, 2 white noise.  restart_interval in MCUs (0 = none).
+ * Table numbering (added to the content class): +0x100 the luma DC table is written as DC table 1 and the
+ * chroma DC table as DC table 0; +0x200 the same for the AC tables; +0x400 the luma quantisation table is
+ * table 1 and the chroma one table 0.  The frame and scan headers name the tables accordingly, so the
+ * decoded image is the same; only a decoder that reads the selectors gets it right.
  * Returns a malloc'd buffer (free with zj_synth_free) and its size in *out_len.
  */
 uint8_t *zj_synth_encode(int w, int h, int hs, int vs, int quality, int content_class, uint64_t seed,
                          int restart_interval, size_t *out_len)
 {
     const int gray = (hs == 0 && vs == 0);
+    const int dc_y = (content_class >> 8) & 1, ac_y = (content_class >> 9) & 1, q_y = (content_class >> 10) & 1;
+    content_class &= 0xff;
     if (gray) hs = vs = 1;
     if (w < 1 || h < 1 || w > 65535 || h > 65535 || hs < 1 || hs > 2 || vs < 1 || vs > 2) return NULL;
     float *Y = (float *)malloc(sizeof(float) * (size_t)w * h);
@@ -260,20 +266,20 @@ uint8_t *zj_synth_encode(int w, int h, int hs, int vs, int quality, int content_
     put(&o, 'J'); put(&o, 'F'); put(&o, 'I'); put(&o, 'F'); put(&o, 0);
     put(&o, 1); put(&o, 1); put(&o, 0); put16(&o, 1); put16(&o, 1); put(&o, 0); put(&o, 0);
     put16(&o, 0xffdb); put16(&o, 2 + 65 * 2); /* one DQT segment, two tables, zig-zag order */
-    put(&o, 0); for (int i = 0; i < 64; i++) put(&o, ql[k_zz2nat[i]]);
-    put(&o, 1); for (int i = 0; i < 64; i++) put(&o, qc[k_zz2nat[i]]);
+    put(&o, q_y); for (int i = 0; i < 64; i++) put(&o, ql[k_zz2nat[i]]);
+    put(&o, 1 - q_y); for (int i = 0; i < 64; i++) put(&o, qc[k_zz2nat[i]]);
     if (gray) {
         put16(&o, 0xffc0); put16(&o, 11); put(&o, 8); put16(&o, h); put16(&o, w); put(&o, 1);
-        put(&o, 1); put(&o, 0x11); put(&o, 0);
+        put(&o, 1); put(&o, 0x11); put(&o, q_y);
     } else {
         put16(&o, 0xffc0); put16(&o, 17); put(&o, 8); put16(&o, h); put16(&o, w); put(&o, 3);
-        put(&o, 1); put(&o, (hs << 4) | vs); put(&o, 0);
-        put(&o, 2); put(&o, 0x11); put(&o, 1);
-        put(&o, 3); put(&o, 0x11); put(&o, 1);
+        put(&o, 1); put(&o, (hs << 4) | vs); put(&o, q_y);
+        put(&o, 2); put(&o, 0x11); put(&o, 1 - q_y);
+        put(&o, 3); put(&o, 0x11); put(&o, 1 - q_y);
     }
     const uint8_t *hb[4] = {k_dc_lum_bits, k_ac_lum_bits, k_dc_chr_bits, k_ac_chr_bits};
     const uint8_t *hv[4] = {k_dc_vals, k_ac_lum_vals, k_dc_vals, k_ac_chr_vals};
-    const int hinfo[4] = {0x00, 0x10, 0x01, 0x11};
+    const int hinfo[4] = {0x00 | dc_y, 0x10 | ac_y, 0x00 | (1 - dc_y), 0x10 | (1 - ac_y)};
     for (int t = 0; t < 4; t++) { /* four DHT segments */
         int n = 0;
         for (int i = 0; i < 16; i++) n += hb[t][i];
@@ -284,10 +290,11 @@ uint8_t *zj_synth_encode(int w, int h, int hs, int vs, int quality, int content_
     if (restart_interval > 0) { put16(&o, 0xffdd); put16(&o, 4); put16(&o, restart_interval); }
     if (gray) {
         put16(&o, 0xffda); put16(&o, 8); put(&o, 1);
-        put(&o, 1); put(&o, 0x00);
+        put(&o, 1); put(&o, (dc_y << 4) | ac_y);
     } else {
         put16(&o, 0xffda); put16(&o, 12); put(&o, 3);
-        put(&o, 1); put(&o, 0x00); put(&o, 2); put(&o, 0x11); put(&o, 3); put(&o, 0x11);
+        const int sy = (dc_y << 4) | ac_y, sc = ((1 - dc_y) << 4) | (1 - ac_y);
+        put(&o, 1); put(&o, sy); put(&o, 2); put(&o, sc); put(&o, 3); put(&o, sc);
     }
     put(&o, 0); put(&o, 63); put(&o, 0);
 

@@ -30,3 +30,16 @@ def fixture_bytes(name):
 
 
 FIXTURES = ["porsche.jpg", "profile.jpg", "test-baseline.jpg", "out.jpg", "large.jpg"]
+
+
+def band_file(data: bytes, band) -> bytes:
+    """A standalone JPEG file for a band of a restart-marked image (zj_image_band): the parent's headers with
+    the frame height replaced by the band's, the band's entropy-coded bytes, EOI.  What a rank that only
+    receives its band would be decoding; lets the CPU oracle decode the band on its own."""
+    import ctypes as C
+    sof = data.index(b"\xff\xc0")
+    sos = data.index(b"\xff\xda", sof)
+    scan0 = sos + 2 + ((data[sos + 2] << 8) | data[sos + 3])
+    head = bytearray(data[:scan0])
+    head[sof + 5], head[sof + 6] = band.height >> 8, band.height & 255
+    return bytes(head) + C.string_at(band.image.scan, band.image.scan_len) + b"\xff\xd9"

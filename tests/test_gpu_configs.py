@@ -1,0 +1,138 @@
+"""GPU tests of the configurations the headline metric names beyond the 1080p batch, and of the pieces around
+the library: table selectors other than the reference's hard-wired ones, the mixed 1080p / 4K job decoded in
+sub-batches of one workspace, the 16384x16384 restart-marked image whole and in eight bands, and the
+command-line driver."""
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, band_file, fixture_bytes
+from oracle import oracle
+
+import jpeg_decoder_amd as J
+from jpeg_decoder_amd import shard, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = J.Context(0)
+    yield c
+    c.close()
+
+
+def test_table_selectors_other_than_the_hard_wired_ones(ctx):
+    """E4: luma tables stored under id 1 (DC, AC and quantisation tables in every combination), chroma under id 0,
+    headers naming them accordingly; src/decoder.rs:171-173 hard-wires Y -> 0, C -> 1 and :368-370 skips the scan
+    header.  One batch holds all combinations, so table sets with different numbering sit side by side."""
+    files = []
+    for (hs, vs, ri, w, h) in [(2, 2, 3, 333, 211), (1, 1, 0, 200, 120), (2, 1, 0, 150, 90), (0, 0, 2, 100, 60)]:
+        files += [synth.encode(w, h, hs, vs, 90, opt << 8, 40 + opt, ri) for opt in range(8)]
+    imgs = [J.ParsedImage(f) for f in files]
+    assert any(im.image.td[0] == 1 and im.image.ta[0] == 0 for im in imgs) and any(im.image.tq[0] == 1 for im in imgs)
+    for sb in (0, 1024):
+        rgb, st, coef = J.decode_images(ctx, imgs, subseq_bits=sb, want_coef=True)
+        for f, r, s_, c in zip(files, rgb, st, coef):
+            ref = oracle.decode(f)
+            assert s_ == 0 and np.array_equal(c, ref.qcoef) and np.array_equal(r, ref.rgb)
+
+
+def test_mixed_1080p_and_4k_job_in_sub_batches(ctx):
+    """Config 4 in small: 1920x1080 and 3840x2160 images, 4:4:4 and 4:2:0, class by index bits as in the
+    benchmark, partitioned over two ranks by scan bytes; each rank's share decoded in sub-batches that share one
+    workspace; every image compared with the oracle, pixels and coefficients."""
+    import torch
+    classes = [(1920, 1080, 2, 2), (3840, 2160, 2, 2), (1920, 1080, 1, 1), (3840, 2160, 1, 1)]
+    files = {c: synth.encode(*classes[c], 90, 0, 500 + c, 0) for c in range(4)}
+    refs = {c: oracle.decode(f) for c, f in files.items()}
+    parsed = {c: J.ParsedImage(f) for c, f in files.items()}
+    job = [i & 3 for i in range(16)]
+    parts = shard.partition_batch([len(files[c]) for c in job], 2)
+    loads = [sum(len(files[job[i]]) for i in p) for p in parts]
+    assert sorted(parts[0] + parts[1]) == list(range(16)) and abs(loads[0] - loads[1]) <= max(len(f) for f in files.values())
+    for mine in parts:
+        groups = [[job[i] for i in mine[g: g + 3]] for g in range(0, len(mine), 3)]
+        est = [J.Workspace.estimate([parsed[c] for c in g]) for g in groups]
+        ws = J.Workspace(ctx, max(e[1] for e in est), max(e[0] for e in est), len(groups))
+        batches = [J.Batch(ctx, [parsed[c] for c in g], workspace=ws, slot=k) for k, g in enumerate(groups)]
+        outs = [b.alloc_rgb() for b in batches]
+        for rep in range(2):
+            for b, o in zip(batches, outs):
+                b.decode(o)
+        for b, o, g in zip(batches, outs, groups):
+            assert not b.finish().any()
+            for t, c in zip(o, g):
+                w, h = classes[c][0], classes[c][1]
+                assert torch.equal(t[:, : w * 3].reshape(h, w, 3).cpu(), torch.from_numpy(refs[c].rgb)), c
+        # coefficients: the arena holds the last decoded sub-batch
+        batches[0].decode(outs[0])
+        assert not batches[0].finish().any()
+        for i, c in enumerate(groups[0]):
+            assert np.array_equal(batches[0].coefficients(i), refs[c].qcoef)
+        assert all(b.counters() == (0, 0, 0) for b in batches)
+        for b in batches:
+            b.close()
+        ws.close()
+
+
+def test_16384_square_restart_image_whole_and_in_eight_bands(ctx):
+    """Config 5 at full size: one 16384x16384 4:2:0 image with a restart interval of 16 MCUs (65 536 intervals),
+    decoded whole and as the eight bands eight ranks would take.  The image is sixteen repetitions of one
+    1024-row strip (restart intervals are independent), so the oracle decodes the strip once and every
+    1024 rows of both decodes must equal it; the bands must also equal the whole decode's CRC."""
+    import torch
+    size, strip_h, reps = 16384, 1024, 16
+    data = synth.encode_tiled(size, strip_h, reps, 2, 2, 90, 0, 77, 16)
+    ref = torch.from_numpy(oracle.decode(synth.encode(size, strip_h, 2, 2, 90, 0, 77, 16)).rgb).to("cuda:0")
+    p = J.ParsedImage(data)
+    assert (p.width, p.height, p.image.restart_interval) == (size, size, 16)
+    whole = torch.empty((size, size * 3), dtype=torch.uint8, device="cuda:0")
+    b = J.Batch(ctx, [p])
+    b.decode([whole])
+    assert not b.finish().any()
+    assert b.counters() == (0, 0, 0)
+    b.close()
+    for k in range(reps):
+        assert torch.equal(whole[k * strip_h: (k + 1) * strip_h].reshape(strip_h, size, 3), ref), f"strip {k} of the whole decode"
+    mcux, mcuy, _, mh = shard.mcu_geometry(size, size, 2, 2)
+    bands = shard.band_rows(mcux, mcuy, 16, 8)
+    assert bands == [(128 * r, 128) for r in range(8)]
+    gathered = torch.empty_like(whole)
+    for (r0, n) in bands:  # one rank after the other on this GPU, each decoding straight into its rows
+        bb = J.Batch(ctx, [p.band(r0, n)])
+        bb.decode([gathered[r0 * mh: (r0 + n) * mh]])
+        assert not bb.finish().any()
+        bb.close()
+    assert torch.equal(gathered, whole)
+    # one band as a standalone file through the oracle (2 048 rows, a few seconds of CPU)
+    alone = oracle.decode(band_file(data, p.band(3 * 128, 128)))
+    assert alone.status == 0
+    assert zlib.crc32(alone.rgb.tobytes()) == zlib.crc32(whole[3 * 2048: 4 * 2048].cpu().numpy().tobytes())
+
+
+def test_command_line_driver_writes_the_reference_output(tmp_path):
+    """The zj_decode binary (C++ zj::Decoder over the C ABI; counterpart of examples/decode.rs:1-9, which decodes
+    test-images/profile.jpg to ./out.ppm): out.ppm must be the header of src/decoder.rs:580 and the oracle's pixels."""
+    exe = os.path.join(ROOT, "jpeg-decoder_amd", "zj_decode")
+    assert os.access(exe, os.X_OK)
+    r = subprocess.run([exe, os.path.join(GOLDEN, "profile.jpg")], cwd=tmp_path, capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stderr
+    blob = open(tmp_path / "out.ppm", "rb").read()
+    ref = oracle.decode(fixture_bytes("profile.jpg"))
+    head = b"P6\n400 400\n255\n"
+    assert blob.startswith(head) and blob[len(head):] == ref.rgb.tobytes()
+    # -o, a 4:2:0 file with a width that is no multiple of 8, and a file that is not a JPEG
+    r = subprocess.run([exe, os.path.join(GOLDEN, "out.jpg"), "-o", str(tmp_path / "o2.ppm")], capture_output=True, text=True, timeout=100)
+    assert r.returncode == 0, r.stderr
+    blob = open(tmp_path / "o2.ppm", "rb").read()
+    ref = oracle.decode(fixture_bytes("out.jpg"))
+    head = b"P6\n1015 1000\n255\n"
+    assert blob.startswith(head) and blob[len(head):] == ref.rgb.tobytes()
+    bad = tmp_path / "bad.jpg"
+    bad.write_bytes(b"not a jpeg")
+    r = subprocess.run([exe, str(bad)], cwd=tmp_path, capture_output=True, text=True, timeout=100)
+    assert r.returncode != 0 and "decode failed" in r.stderr

@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import FIXTURES, ROOT, fixture_bytes
+from conftest import band_file, FIXTURES, ROOT, fixture_bytes
 from oracle import oracle
 
 import jpeg_decoder_amd as J
@@ -80,13 +80,14 @@ def test_restart_offsets_and_bands():
     for k in range(1, n):
         assert scan[offs[k] - 2] == 0xFF and 0xD0 <= scan[offs[k] - 1] <= 0xD7
     full = oracle.decode(data)
-    # a band is a valid standalone image: rebuild a file around it with the oracle as checker
+    # a band is a valid standalone image: a file built around it decodes to the same rows of the whole image
     band = p.band(2, 3)
     assert (band.width, band.height) == (256, 48)
+    alone = oracle.decode(band_file(data, band))
+    assert alone.status == 0 and np.array_equal(alone.rgb, full.rgb[32:80])
+    assert np.array_equal(alone.qcoef, full.qcoef[2 * 16 * 6: 5 * 16 * 6])
     with pytest.raises(J.DecodeError):
         J.ParsedImage(synth.encode(256, 128, 2, 2, seed=5, restart_interval=5)).band(1, 2)
-    # rows 2..4 of the full decode are what the band must produce
-    assert full.rgb[32:80].shape == (48, 256, 3)
 
 
 SIM_CASES = [(f, sb) for f in ["porsche.jpg", "profile.jpg", "test-baseline.jpg", "out.jpg"] for sb in (512, 1024, 4096, 65536)]

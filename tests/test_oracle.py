@@ -177,3 +177,62 @@ def test_one_component_frames():
         px = np.clip(np.trunc(oracle.idct(blk) + np.float32(128)), 0, 255).astype(np.uint8).reshape(8, 8)
         hh, ww = min(8, h), min(8, w)
         assert np.array_equal(g.rgb[:hh, :ww, 0], px[:hh, :ww])
+
+
+def _ycc(rgb):
+    """BT.601 full-range luma and chroma of an RGB array (float)."""
+    r, g, b = [rgb[..., k].astype(float) for k in range(3)]
+    return (0.299 * r + 0.587 * g + 0.114 * b, 128 - 0.168736 * r - 0.331264 * g + 0.5 * b, 128 + 0.5 * r - 0.418688 * g - 0.081312 * b)
+
+
+@pytest.mark.parametrize("case", ["out.jpg", "synth420", "synth420_restart", "synth422", "synth440", "gray", "gray_restart", "swapped_ids"])
+def test_libjpeg_loose_crosscheck_of_the_defined_extensions(case):
+    """Subsampled, restart-marked and one-component files against libjpeg (via Pillow, build container only), in
+    YCbCr so that libjpeg's colour conversion stays out of it.  libjpeg interpolates the chroma planes where
+    the oracle replicates samples, so chroma is compared as means over the chroma sample's pixels, loosely;
+    the luma plane is compared pixel by pixel.  The bars are far below what a wrong MCU block order, a shifted
+    or swapped chroma plane or a missed predictor reset at a restart marker would produce (tens of levels)."""
+    PIL = pytest.importorskip("PIL.Image")
+    hs, vs = 2, 2
+    if case == "out.jpg":
+        data = fixture_bytes("out.jpg")
+    else:
+        hs, vs = {"synth422": (2, 1), "synth440": (1, 2), "gray": (0, 0), "gray_restart": (0, 0)}.get(case, (2, 2))
+        ri = 5 if "restart" in case else 0
+        cls = 0x700 if case == "swapped_ids" else 0
+        data = synth.encode(333, 211, hs, vs, 90, cls, 17, ri)
+    ref = oracle.decode(data)
+    assert ref.status == 0
+    im = PIL.open(io.BytesIO(data))
+    if im.mode == "L":
+        lj = np.asarray(im).astype(float)
+        assert np.array_equal(ref.rgb[..., 0], ref.rgb[..., 1]) and np.array_equal(ref.rgb[..., 0], ref.rgb[..., 2])
+        d = np.abs(lj - ref.rgb[..., 0])
+        assert d.mean() < 1.0 and d.max() <= 4, (d.mean(), d.max())
+        return
+    im.draft("YCbCr", im.size)
+    assert im.mode == "YCbCr"
+    lj = np.asarray(im).astype(float)
+    y, cb, cr = _ycc(ref.rgb)
+    d = np.abs(lj[..., 0] - y)
+    assert d.mean() < 1.0 and (d <= 4).mean() > 0.999 and d.max() <= 16, (d.mean(), d.max())
+    h, w = y.shape
+    mh, mw = max(vs, 1), max(hs, 1)  # pixels per chroma sample
+    hh, ww = h // mh * mh, w // mw * mw
+
+    def means(a):
+        return a[:hh, :ww].reshape(hh // mh, mh, ww // mw, mw).mean((1, 3))
+    for ours, theirs in ((cb, lj[..., 1]), (cr, lj[..., 2])):
+        d = np.abs(means(ours) - means(theirs))
+        assert d.mean() < 6.0, d.mean()
+
+
+def test_table_selectors_are_read_from_the_headers():
+    """E4: the same image with the luma tables stored under id 1 (DC, AC, quantisation, in every combination) and
+    the headers naming them accordingly decodes to the same coefficients and pixels; the reference's hard-wired
+    Y -> 0, C -> 1 (src/decoder.rs:171-173) would not."""
+    for (hs, vs, ri) in [(2, 2, 3), (1, 1, 0), (0, 0, 0)]:
+        base = oracle.decode(synth.encode(160, 120, hs, vs, 90, 0, 5, ri))
+        for opt in range(1, 8):
+            r = oracle.decode(synth.encode(160, 120, hs, vs, 90, opt << 8, 5, ri))
+            assert r.status == 0 and np.array_equal(r.qcoef, base.qcoef) and np.array_equal(r.rgb, base.rgb), (hs, vs, opt)

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT
+from conftest import ROOT, band_file
 from oracle import oracle
 
 import jpeg_decoder_amd as J
@@ -45,12 +45,12 @@ def test_band_rows_follow_restart_boundaries():
     assert sum(b[1] for b in bands) == 2 and bands[-1][1] == 0
 
 
-def _decode_band_with_oracle(parsed, row0, nrows, full_rgb):
-    """Stand-in device: checks that the band is a valid standalone scan by re-wrapping it in a file."""
+def _decode_band_with_oracle(data, parsed, row0, nrows):
+    """Stand-in device: the band, wrapped into a file of its own, decoded by the CPU oracle."""
     band = parsed.band(row0, nrows)
-    mh = 8 * parsed.image.vsamp[0]
-    y0 = row0 * mh
-    return full_rgb[y0:y0 + band.height]
+    r = oracle.decode(band_file(data, band))
+    assert r.status == 0 and r.rgb.shape[:2] == (band.height, band.width)
+    return r.rgb
 
 
 def _free_port():
@@ -74,7 +74,7 @@ def _worker(rank, world, port, data, q):
         bands = shard.band_rows(mcux, mcuy, im.restart_interval, world)
         full = oracle.decode(data).rgb
         row0, nrows = bands[rank]
-        mine = _decode_band_with_oracle(parsed, row0, nrows, full) if nrows else np.zeros((0, im.width, 3), np.uint8)
+        mine = _decode_band_with_oracle(data, parsed, row0, nrows) if nrows else np.zeros((0, im.width, 3), np.uint8)
         local = torch.from_numpy(np.ascontiguousarray(mine)).reshape(mine.shape[0], -1)
         shapes = [(min(n * mh, im.height - r0 * mh) if n else 0, im.width * 3) for (r0, n) in bands]
         out = shard.gather_bands(local, shapes, rank, world, root=0)
@@ -106,3 +106,17 @@ def test_two_rank_band_gather_gloo():
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
     assert q.get(timeout=5) is True
+
+
+def test_bands_decoded_alone_tile_the_image():
+    """Every band of a restart-marked image, decoded on its own by the oracle from a file of its own, equals the
+    same rows of the whole decode: 1 to 5 ranks, a height that is no multiple of the MCU height, 4:2:0 and 4:2:2."""
+    for (w, h, hs, vs, ri) in [(256, 150, 2, 2, 16), (320, 96, 2, 1, 10), (128, 128, 1, 1, 8)]:
+        data = synth.encode(w, h, hs, vs, seed=33, restart_interval=ri)
+        parsed = J.ParsedImage(data)
+        full = oracle.decode(data).rgb
+        mcux, mcuy, mw, mh = shard.mcu_geometry(w, h, hs, vs)
+        for world in (1, 2, 3, 5):
+            bands = shard.band_rows(mcux, mcuy, ri, world)
+            rows = [_decode_band_with_oracle(data, parsed, r0, n) for (r0, n) in bands if n]
+            assert np.array_equal(np.concatenate(rows, 0), full), (w, h, world)

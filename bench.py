@@ -9,6 +9,9 @@ anything touches a GPU) and prints rank 0's line.  Workloads (the configurations
 
   c3 (default)  4096 synthetic 1920x1080 4:2:0 q90 baseline JPEGs per GPU (64 distinct seeds, each uploaded to its
                 own HBM location).  Batches shard by image: no collective, weak scaling.
+  c2            single-image latency: tests/golden/large.jpg (7680x4320 4:4:4, no restart markers: one self-synchronising
+                stream) as the timed workload, porsche.jpg beside it.  Replicas only: an image without restart markers
+                does not shard.
   c4            a mixed job of 1920x1080 / 3840x2160 x 4:4:4 / 4:2:0 images (index bits pick the class), 8192 per
                 GPU by default, partitioned over the ranks by scan bytes (longest first), decoded in sub-batches
                 that share one workspace (coefficient arena reused); all plans and pixels stay resident.
@@ -40,7 +43,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="c3", choices=["c3", "c4", "c5"])
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--images", type=int, default=0, help="images per GPU (weak scaling); 0 = 4096 for c3, 8192 for c4")
     ap.add_argument("--sub-batch", type=int, default=1024, help="c4: images per sub-batch of the shared workspace")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic images (seeds), cycled")
@@ -374,6 +377,50 @@ def cpu_baseline(files, pixels, nsample, threads, what):
             "single_thread_value": round(pixels[0] / t_one / 1e6, 2)}
 
 
+# ------------------------------------------------------------------------------------------ c2
+def run_c2(a, D):
+    import numpy as np
+    import jpeg_decoder_amd as J
+    torch, dev = D.torch, D.dev
+    stream = torch.cuda.Stream(device=dev)
+    ctx = J.Context(dev, stream=stream.cuda_stream)
+    golden = os.path.join(ROOT, "tests", "golden")
+    info = json.load(open(os.path.join(golden, "golden.json")))["fixtures"]
+    res, main = {}, None
+    for name in ("porsche.jpg", "large.jpg"):
+        data = open(os.path.join(golden, name), "rb").read()
+        p = J.ParsedImage(data)
+        b = J.Batch(ctx, [p], a.subseq_bits)
+        outs = b.alloc_rgb()
+
+        def check():
+            assert not b.finish().any()
+        wall, dev_ms = timed_steps(D, stream, lambda: b.decode(outs), a.steps, a.warmup, check)
+        check()
+        kt = profile_kernels([b], lambda _b: outs)
+        bc = b.byte_counts()
+        crc = zlib.crc32(np.ascontiguousarray(outs[0][:, : p.width * 3].cpu().numpy()).tobytes())
+        ok = crc == info[name]["rgb_crc"] and zlib.crc32(b.coefficients(0).tobytes()) == info[name]["qcoef_crc"]
+        res[name] = {"pixels": p.width * p.height, "ms": round(dev_ms / a.steps, 4), "wall_ms": round(wall / a.steps * 1e3, 4),
+                     "kernel_ms": {k: round(v, 4) for k, v in kt.items()}, "equals_committed_oracle_hashes": bool(ok),
+                     "fast_path": fast_path_fields([b]),
+                     "roofline_end_to_end_frac": round((bc["scan"] + 2 * bc["coef"] + bc["rgb"]) / (dev_ms / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if name == "large.jpg":
+            main = (wall, dev_ms, kt, bc, p)
+        b.close()
+    ctx.close()
+    if D.rank != 0:
+        return None
+    wall, dev_ms, kt, bc, p = main
+    assert all(r["equals_committed_oracle_hashes"] for r in res.values()), res
+    return {"metric": METRIC, "value": round(p.width * p.height * D.world / (wall / a.steps) / 1e6, 1), "unit": "MP/s", "n_gpus": D.world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/i16 entropy decode, f32 IDCT+colour", "data": "fixture",
+            "config": {"workload": "c2: single-image latency, tests/golden/large.jpg (7680x4320 4:4:4, one stream without restart markers); "
+                                   "porsche.jpg beside it", "timing": "device-resident", "sharding": "replicas only"},
+            "roofline": roofline_fields(kt, bc["scan"], bc["coef"], bc["rgb"]), "images": res}
+
+
 # ------------------------------------------------------------------------------------------ c4
 C4_CLASSES = [(1920, 1080, 2, 2), (3840, 2160, 2, 2), (1920, 1080, 1, 1), (3840, 2160, 1, 1)]  # index bit 0: size, bit 1: sampling
 
@@ -607,7 +654,7 @@ def main():
                          "torch.distributed.run with --nproc-per-node equal to --gpus\n")
         return 2
     D = Dist(a)
-    result = {"c3": run_c3, "c4": run_c4, "c5": run_c5}[a.config](a, D)
+    result = {"c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5}[a.config](a, D)
     D.close()
     if D.rank == 0:
         print(json.dumps(result), flush=True)

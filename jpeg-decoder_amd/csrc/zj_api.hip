@@ -638,7 +638,6 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     while (chunk_seg.size() % 4u) chunk_seg.push_back(ZJ_NONE); // whole workgroups
     ZjParams &P = b->P;
     bool ok = true;
-    P.imgs = dev_upload(b, b->imgs);
     P.segs = dev_upload(b, b->segs);
     P.chunk_seg = dev_upload(b, chunk_seg);
     P.blk256_img = dev_upload(b, blk256_img);
@@ -658,8 +657,23 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     std::vector<uint16_t> wluts(luts.size());
     for (size_t t = 0; t < luts.size() / ZJ_TBL_ENTRIES; t++)
         zj_build_walk_table(&luts[t * ZJ_TBL_ENTRIES], (t & 3u) < 2u, &wluts[t * ZJ_TBL_ENTRIES]);
+    std::vector<uint32_t> ptabs(luts.size() / ZJ_TBL_ENTRIES * ZJ_PT_ENTRIES);
+    std::vector<uint8_t> pair_needs_canon(luts.size() / ZJ_SET_ENTRIES, 0);
+    for (size_t t = 0; t < luts.size() / ZJ_TBL_ENTRIES; t++) {
+        uint32_t *pt = &ptabs[t * ZJ_PT_ENTRIES];
+        (void)zj_build_pair_table(&canons[t], (t & 3u) < 2u, pt);
+        for (uint32_t e = 0; e < (uint32_t)ZJ_PL1_SIZE; e++) {
+            if (!(pt[e] & 0x80000000u)) continue;
+            if (l2_cap == 0) pt[e] = 0x80000000u; // the testing aid that drops the second level applies here too
+            if (((pt[e] >> 24) & 7u) == 0) pair_needs_canon[t / 4] = 1;
+        }
+    }
+    for (size_t i = 0; i < n; i++)
+        if (b->imgs[i].flags && pair_needs_canon[b->imgs[i].lut_set]) b->imgs[i].flags |= 4u;
     P.luts = dev_upload(b, luts);
     P.wluts = dev_upload(b, wluts);
+    P.ptabs = dev_upload(b, ptabs);
+    P.imgs = dev_upload(b, b->imgs); // after the table forms are known: the descriptors carry their flags
     P.canons = dev_upload(b, canons);
     P.qts = dev_upload(b, qts);
     P.raw = raw;
@@ -667,7 +681,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     P.flags = dev_alloc<uint32_t>(b, 4, true);
     b->d_rgb = dev_alloc<uint8_t *>(b, n, true);
     b->d_stride = dev_alloc<size_t>(b, n, true);
-    ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.wluts && P.canons && P.qts &&
+    ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.wluts && P.ptabs && P.canons && P.qts &&
          P.ptile_seg && P.tile_seg && P.dtile_seg && P.status && P.flags && b->d_rgb && b->d_stride;
     if (ok && mode == ZJ_ALLOC_NONE) {
         // the rest of the range is this call's scratch
@@ -752,7 +766,7 @@ extern "C" int zj_workspace_estimate(const zj_image *images, size_t n, size_t *p
         const uint64_t utiles = len / ZJ_UNSTUFF_TILE + 2 * S, ptiles = win / 256 + S, dtiles = M / 256 + S;
         const uint64_t mtiles = len / ZJ_MARK_TILE + 1;
         plan += align_up((size_t)len, 16) + 16 + S * sizeof(ZjSegDev) + 4 * (chunks + B / 256 + (M / 128 + 1) + ptiles + utiles + dtiles) + 8 * (M / 16 + 2);
-        plan += 2 * ZJ_SET_ENTRIES * 2 + 4 * sizeof(ZjCanon) + 3 * 64 * 2;  // a table set and quantisation tables of its own
+        plan += 2 * ZJ_SET_ENTRIES * 2 + ZJ_PSET_ENTRIES * 4 + 4 * sizeof(ZjCanon) + 3 * 64 * 2;  // a table set (three forms) and quantisation tables of its own
         plan += sizeof(ZjMarkImg) + 8 * mtiles + 4 + 4 * (S + 1);           // restart-marker search
         scr += 16 * dtiles + 8 * (utiles + S) + 2 * (len + 112 * S) + 8 * S + 8 * win + 7 * B + 128 * B;
     }

@@ -40,6 +40,26 @@
 //                         pattern that is no code: consume 1 bit, advance as an EOB / a DC symbol)
 //   entry, bit 15 set  :  first level only: [14:12] nb, [8:0] sub-table offset, as above
 
+// The sync pass, which walks every symbol of every stream once without producing coefficients, uses a third
+// form with up to two symbols per lookup ("pair entries"): ZJ_PT_ENTRIES uint32 entries per table, a first
+// level indexed by the next ZJ_PL1_BITS bits followed by second-level sub-tables for longer codes.
+//   entry, bit 31 clear:  [5:0]   t1   bits of the first symbol, code and value (1..32)
+//                         [11:6]  t12  bits of both symbols (= t1 when the entry holds one symbol)
+//                         [18:12] a1   zig-zag advance of the first symbol (as in a walk entry)
+//                         [25:19] a12  advance of both (= a1 when the entry holds one symbol; a second symbol
+//                                      that is an EOB adds 64)
+//   entry, bit 31 set  :  first level only: [26:24] nb = extra index bits (1..6), [8:0] offset of the sub-table
+//                         inside the second level; nb == 0: use the canonical search.
+// A second symbol is entered only behind an AC symbol that is no EOB, and only when its whole code lies inside
+// the index bits (its value bits need not).  The walk takes it when the first symbol neither ends the block
+// nor reaches the end of the stretch being walked, so the states a walk passes through are those of the
+// symbol-by-symbol walk with some of them skipped -- never a state that walk would not reach.
+#define ZJ_PL1_BITS 10
+#define ZJ_PL1_SIZE 1024
+#define ZJ_PL2_SIZE 256
+#define ZJ_PT_ENTRIES (ZJ_PL1_SIZE + ZJ_PL2_SIZE)
+#define ZJ_PSET_ENTRIES (4 * ZJ_PT_ENTRIES)
+
 // Canonical description of one table, used by the rare fallback path only.
 struct ZjCanon {
     uint16_t ncode[17];   // number of codes of length l (index 1..16)
@@ -67,7 +87,8 @@ struct ZjImgDev {
     uint32_t qt_off[3];     // element offsets of the three components' quantisation tables (64 entries each)
     uint32_t first_strip;   // first global strip index of stage 2
     uint32_t strips_x;      // strips per MCU row
-    uint32_t flags;         // bit 0: supported, bit 1: the table set needs the canonical search for some codes
+    uint32_t flags;         // bit 0: supported, bit 1: the table set needs the canonical search for some codes,
+                            // bit 2: so do its pair tables
     uint32_t first_k1w;     // first workgroup of the write pass
     uint32_t k1w_mcus;      // MCUs per wavefront of the write pass (a multiple of 64)
 };
@@ -463,6 +484,70 @@ ZJ_HD void zj_decode_run(BITS &bits, const uint16_t *wlut, const ZjCanon *canon,
         const uint32_t tot = e & 63u;
         em.block_start(p, isdc ? 1u : 0u);
         const uint32_t z2 = z + ((e >> 6) & 127u);
+        const bool endblk = z2 >= 64u;
+        z = endblk ? 0u : z2;
+        b += endblk ? 1u : 0u;
+        b = (b >= bpm) ? 0u : b;
+        bits.skip(tot);
+        p += tot;
+    }
+    st.p = p; st.b = b; st.z = z;
+}
+
+// Pair entry holding the single symbol of a walk entry.
+ZJ_HD uint32_t zj_pair_single(uint32_t walk_entry)
+{
+    const uint32_t tot = walk_entry & 63u, adv = (walk_entry >> 6) & 127u;
+    return tot | (tot << 6) | (adv << 12) | (adv << 19);
+}
+
+// First-level pair entry for the next bits of the stream (LDS = true: the table is in LDS, kernels only).
+template <bool LDS>
+ZJ_HD uint32_t zj_ptbl_first(const uint32_t *ptbl, uint32_t top32)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (LDS) {
+        const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)ptbl;
+        uint32_t addr;
+        asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(addr) : "v"(top32 >> (32 - ZJ_PL1_BITS)), "v"(base));
+        return *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)addr;
+    }
+#endif
+    return ptbl[top32 >> (32 - ZJ_PL1_BITS)];
+}
+
+template <bool CANON = true, bool LDS = false>
+ZJ_HD uint32_t zj_lookup_pair(const uint32_t *ptbl, const ZjCanon *canon, uint32_t top32, bool isdc)
+{
+    uint32_t e = zj_ptbl_first<LDS>(ptbl, top32);
+    if (e & 0x80000000u) {
+        const uint32_t nb = (e >> 24) & 7u;
+        if (CANON && nb == 0) return zj_pair_single(zj_walk_entry(zj_canon_lookup(canon, top32), isdc));
+        e = ptbl[ZJ_PL1_SIZE + (e & 0x1FFu) + ((top32 >> (32 - ZJ_PL1_BITS - nb)) & ((1u << nb) - 1u))];
+    }
+    return e;
+}
+
+// zj_decode_run with pair entries: the same walk, up to two symbols a step.  `ptab` is a table set of pair
+// entries.  The second symbol of an entry is taken only if the first neither ends the block (by an EOB or
+// by reaching coefficient 63) nor is the last one that starts before `stop`; the states at st.p on return
+// are therefore exactly those of the symbol-by-symbol walk.
+template <class BITS, class EMIT, bool CANON = true, bool LDS = false>
+ZJ_HD void zj_decode_run_pairs(BITS &bits, const uint32_t *ptab, const ZjCanon *canon, uint32_t selw, uint32_t bpm,
+                               ZjState &st, uint32_t stop, EMIT &em)
+{
+    uint32_t p = st.p, b = st.b, z = st.z;
+    while (p < stop) {
+        const uint32_t top = bits.top32();
+        const bool isdc = (z == 0);
+        const uint32_t t = (selw >> (2u * b + (isdc ? 0u : 16u))) & 3u;
+        const uint32_t e = zj_lookup_pair<CANON, LDS>(ptab + t * ZJ_PT_ENTRIES, canon ? canon + t : nullptr, top, t < 2u);
+        const uint32_t t1 = e & 63u, a1 = (e >> 12) & 127u;
+        const uint32_t z1 = z + a1;
+        const bool one = z1 >= 64u || p + t1 >= stop;
+        const uint32_t tot = one ? t1 : ((e >> 6) & 63u);
+        const uint32_t z2 = one ? z1 : z + ((e >> 19) & 127u);
+        em.block_start(p, isdc ? 1u : 0u);
         const bool endblk = z2 >= 64u;
         z = endblk ? 0u : z2;
         b += endblk ? 1u : 0u;

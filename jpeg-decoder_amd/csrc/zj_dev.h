@@ -41,6 +41,7 @@ struct ZjParams {
     int16_t *qcoef;             // [block][64] zig-zag, quantised: the stage seam
     const uint16_t *luts;       // [table set][ZJ_SET_ENTRIES]
     const uint16_t *wluts;      // the same sets as walk entries
+    const uint32_t *ptabs;      // the same sets as pair entries, [table set][ZJ_PSET_ENTRIES]
     const ZjCanon *canons;      // [table set][4]
     const uint16_t *qts;        // quantisation tables widened to 16 bits, 64 entries each, zig-zag order
     const uint32_t *blk256_img; // [block / 256] image

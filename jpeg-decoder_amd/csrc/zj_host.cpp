@@ -320,3 +320,67 @@ void zj_build_walk_table(const uint16_t *tbl, bool isdc, uint16_t *wtbl)
         else wtbl[i] = (uint16_t)zj_walk_entry(e, isdc);
     }
 }
+
+// Pair entries: every first-level index is decoded symbol by symbol with the canonical description, as far
+// as the index bits determine whole codes.
+bool zj_build_pair_table(const ZjCanon *canon, bool isdc, uint32_t *ptbl)
+{
+    struct Code { uint32_t code, len, sym; };
+    std::vector<Code> codes;
+    for (uint32_t l = 1; l <= 16; l++)
+        for (uint32_t i = 0; i < canon->ncode[l]; i++)
+            codes.push_back({(uint32_t)canon->mincode[l] + i, l, canon->symbols[(canon->valptr[l] + i) & 255u]});
+    // the code that the top bits of the 32-bit window `x` begin with, among codes of at most `maxlen` bits
+    auto match = [&](uint32_t x, uint32_t maxlen) -> const Code * {
+        for (const Code &c : codes)
+            if (c.len <= maxlen && (x >> (32u - c.len)) == c.code) return &c;
+        return nullptr;
+    };
+    auto single = [&](const Code *c) { return zj_pair_single(zj_walk_entry(c ? ((c->len << 8) | c->sym) : 0u, isdc)); };
+    const uint32_t invalid = single(nullptr);
+    for (uint32_t i = 0; i < ZJ_PT_ENTRIES; i++) ptbl[i] = invalid;
+    for (uint32_t idx = 0; idx < ZJ_PL1_SIZE; idx++) {
+        const uint32_t x = idx << (32 - ZJ_PL1_BITS);
+        const Code *c1 = match(x, ZJ_PL1_BITS);
+        if (!c1) continue; // no code, or the prefix of longer codes (entered below)
+        uint32_t e = single(c1);
+        const uint32_t t1 = e & 63u, a1 = (e >> 12) & 127u;
+        if (!isdc && a1 < 64u && t1 < (uint32_t)ZJ_PL1_BITS) {
+            const Code *c2 = match(x << t1, ZJ_PL1_BITS - t1);
+            if (c2) {
+                const uint32_t w2 = zj_walk_entry((c2->len << 8) | c2->sym, false);
+                const uint32_t t12 = t1 + (w2 & 63u), a12 = a1 + ((w2 >> 6) & 127u);
+                if (t12 <= 32u) e = t1 | (t12 << 6) | (a1 << 12) | (a12 << 19);
+            }
+        }
+        ptbl[idx] = e;
+    }
+    // second level: one sub-table per first-level prefix that begins longer codes
+    uint32_t used = 0;
+    bool fits = true;
+    for (size_t i = 0; i < codes.size() && fits;) {
+        if (codes[i].len <= (uint32_t)ZJ_PL1_BITS) { i++; continue; }
+        const uint32_t prefix = codes[i].code >> (codes[i].len - ZJ_PL1_BITS);
+        size_t j = i;
+        uint32_t maxlen = 0;
+        while (j < codes.size() && codes[j].len > (uint32_t)ZJ_PL1_BITS && (codes[j].code >> (codes[j].len - ZJ_PL1_BITS)) == prefix) {
+            if (codes[j].len > maxlen) maxlen = codes[j].len;
+            j++;
+        }
+        const uint32_t nb = maxlen - ZJ_PL1_BITS;
+        if (used + (1u << nb) > (uint32_t)ZJ_PL2_SIZE) { fits = false; break; }
+        ptbl[prefix] = 0x80000000u | (nb << 24) | used;
+        for (size_t t = i; t < j; t++) {
+            const uint32_t extra = codes[t].len - ZJ_PL1_BITS;
+            const uint32_t first = (codes[t].code & ((1u << extra) - 1u)) << (nb - extra);
+            for (uint32_t u = 0; u < (1u << (nb - extra)); u++) ptbl[ZJ_PL1_SIZE + used + first + u] = single(&codes[t]);
+        }
+        used += 1u << nb;
+        i = j;
+    }
+    if (!fits) {
+        for (const Code &c : codes)
+            if (c.len > (uint32_t)ZJ_PL1_BITS) ptbl[c.code >> (c.len - ZJ_PL1_BITS)] = 0x80000000u;
+    }
+    return fits;
+}

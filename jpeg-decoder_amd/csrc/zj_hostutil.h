@@ -13,3 +13,8 @@ bool zj_image_supported(const zj_image *im);
 // canonical search, which is how the tests reach that path with ordinary tables)
 bool zj_build_table(const zj_huff *h, uint16_t *tbl, ZjCanon *canon, uint32_t l2_cap = ZJ_L2_SIZE);
 void zj_build_walk_table(const uint16_t *tbl, bool isdc, uint16_t *wtbl);
+
+// The table in pair-entry form (zj_core.h): ZJ_PT_ENTRIES entries.  `canon` is the table's canonical
+// description from zj_build_table.  Returns false when the long codes do not fit the second level; the
+// first-level entries of long prefixes then send the walk to the canonical search.
+bool zj_build_pair_table(const ZjCanon *canon, bool isdc, uint32_t *ptbl);

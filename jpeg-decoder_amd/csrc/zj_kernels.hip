@@ -175,7 +175,7 @@ __device__ __forceinline__ void zj_stage_window(const uint32_t *stream, uint32_t
 // began in the window.
 template <bool CANON>
 __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *stream, uint32_t *bitmap,
-                                                   const uint16_t *lut, const ZjCanon *canon, uint32_t selw,
+                                                   const uint32_t *lut, const ZjCanon *canon, uint32_t selw,
                                                    uint32_t bpm, ZjState &st, uint32_t win, uint32_t end,
                                                    uint32_t *col, ZjBitsLds &bits, bool &primed)
 {
@@ -186,7 +186,7 @@ __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *str
         if (!primed) { bits.init(col, wbase, st.p); primed = true; }
         else bits.rebase(col, wbase, st.p);
         const uint32_t wend = (win + 1u) * ZJ_WIN_BITS;
-        zj_decode_run<ZjBitsLds, ZjBitsLds, CANON, true>(bits, lut, canon, selw, bpm, st, wend < end ? wend : end, bits);
+        zj_decode_run_pairs<ZjBitsLds, ZjBitsLds, CANON, true>(bits, lut, canon, selw, bpm, st, wend < end ? wend : end, bits);
         // slots up to the reader's current word hold bitmap words, the ones behind it still stream words
         bits.slot[0] = bits.bm;
         const uint32_t taken = bits.words_done(col) + 1u;
@@ -426,7 +426,7 @@ __device__ __forceinline__ uint32_t zj_load_coherent(const uint32_t *p)
 }
 
 template <bool CANON>
-__device__ __forceinline__ void zj_k1a_body(const ZjParams &P, const ZjImgDev &im, const uint16_t *lut, uint32_t *col, uint32_t chunk,
+__device__ __forceinline__ void zj_k1a_body(const ZjParams &P, const ZjImgDev &im, const uint32_t *lut, uint32_t *col, uint32_t chunk,
                                             uint32_t lane)
 {
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
@@ -484,7 +484,7 @@ __device__ __forceinline__ void zj_k1a_body(const ZjParams &P, const ZjImgDev &i
 // chunk do; G = 1 is the plain sequential walk of a restart interval from its known start.  Everything
 // that is per segment -- stream, bitmap, record area, sizes -- is per lane here.
 template <bool CANON>
-__device__ __forceinline__ void zj_k1a_body_packed(const ZjParams &P, const ZjImgDev &im, const uint16_t *lut, uint32_t *col, uint32_t chunk,
+__device__ __forceinline__ void zj_k1a_body_packed(const ZjParams &P, const ZjImgDev &im, const uint32_t *lut, uint32_t *col, uint32_t chunk,
                                                    uint32_t seg0, uint32_t G, uint32_t lane)
 {
     const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u;
@@ -546,22 +546,29 @@ __device__ __forceinline__ void zj_k1a_body_packed(const ZjParams &P, const ZjIm
     }
 }
 
+__device__ __forceinline__ void load_ptab_to_lds(uint32_t *lds, const uint32_t *src)
+{
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d4 = reinterpret_cast<uint4 *>(lds);
+    for (uint32_t i = threadIdx.x; i < ZJ_PSET_ENTRIES * 4u / 16u; i += blockDim.x) d4[i] = s4[i];
+}
+
 __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
+    __shared__ __attribute__((aligned(16))) uint32_t lut[ZJ_PSET_ENTRIES]; // pair entries: up to two symbols a lookup
     __shared__ uint32_t win[4][ZJ_WIN_SLOTS * 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t *col = &win[wave][lane];
     const uint32_t chunk = blockIdx.x * 4u + wave;
     const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
     const ZjImgDev im = P.imgs[P.segs[seg_first].img]; // by value: a reference would be read again after every store
-    load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
+    load_ptab_to_lds(lut, P.ptabs + (size_t)im.lut_set * ZJ_PSET_ENTRIES);
     __syncthreads();
     const uint32_t seg = P.chunk_seg[chunk];
     if (seg == ZJ_NONE || P.segs[seg].lanes != 64u) return; // wave-uniform: a padding chunk, or one for the packed kernel
     // the four chunks of a workgroup share a table set, not necessarily an image: layout and selectors are the wavefront's own
     const ZjImgDev imw = P.imgs[P.segs[seg].img];
-    if (imw.flags & 2u) zj_k1a_body<true>(P, imw, lut, col, chunk, lane);
+    if (imw.flags & 4u) zj_k1a_body<true>(P, imw, lut, col, chunk, lane);
     else zj_k1a_body<false>(P, imw, lut, col, chunk, lane);
 }
 
@@ -569,7 +576,7 @@ __global__ __launch_bounds__(256) void zj_k1a_sync(ZjParams P)
 // (launched only when the batch has packed chunks).
 __global__ __launch_bounds__(256) void zj_k1a_sync_packed(ZjParams P)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
+    __shared__ __attribute__((aligned(16))) uint32_t lut[ZJ_PSET_ENTRIES];
     __shared__ uint32_t win[4][ZJ_WIN_SLOTS * 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t *col = &win[wave][lane];
@@ -582,14 +589,14 @@ __global__ __launch_bounds__(256) void zj_k1a_sync_packed(ZjParams P)
     if (!any) return;
     const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
     const ZjImgDev im = P.imgs[P.segs[seg_first].img]; // by value: a reference would be read again after every store
-    load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
+    load_ptab_to_lds(lut, P.ptabs + (size_t)im.lut_set * ZJ_PSET_ENTRIES);
     __syncthreads();
     const uint32_t seg = P.chunk_seg[chunk];
     if (seg == ZJ_NONE) return;
     const uint32_t G = P.segs[seg].lanes;
     if (G == 64u) return;
     const ZjImgDev imw = P.imgs[P.segs[seg].img]; // a packed chunk holds segments of one image
-    if (imw.flags & 2u) zj_k1a_body_packed<true>(P, imw, lut, col, chunk, seg, G, lane);
+    if (imw.flags & 4u) zj_k1a_body_packed<true>(P, imw, lut, col, chunk, seg, G, lane);
     else zj_k1a_body_packed<false>(P, imw, lut, col, chunk, seg, G, lane);
 }
 

@@ -230,3 +230,64 @@ extern "C" void zjsim_seg_layout(uint64_t raw_bits, uint32_t target, uint32_t sm
 {
     zj_seg_layout(raw_bits, target, small_target, subbits, nsub, lanes);
 }
+
+// The walk with pair entries against the symbol-by-symbol walk on a random bit stream: from random states,
+// over stretches that end at random bits, both must stop in the same state and mark the same block starts.
+// Returns mismatches, -1 if the table is no prefix code.
+extern "C" int zjsim_pair_walk_check(const zj_huff *dc, const zj_huff *ac, uint32_t l2_cap, uint32_t ntests, uint64_t seed, uint32_t *pairs_taken)
+{
+    std::vector<uint16_t> tbl(ZJ_SET_ENTRIES), wtbl(ZJ_SET_ENTRIES);
+    std::vector<uint32_t> ptab(ZJ_PSET_ENTRIES);
+    ZjCanon canon[4];
+    const zj_huff *t4[4] = {dc, dc, ac, ac};
+    for (int t = 0; t < 4; t++) {
+        if (!zj_build_table(t4[t], &tbl[t * ZJ_TBL_ENTRIES], &canon[t], l2_cap)) return -1;
+        zj_build_walk_table(&tbl[t * ZJ_TBL_ENTRIES], t < 2, &wtbl[t * ZJ_TBL_ENTRIES]);
+        zj_build_pair_table(&canon[t], t < 2, &ptab[t * ZJ_PT_ENTRIES]);
+        if (l2_cap == 0)
+            for (uint32_t e = 0; e < (uint32_t)ZJ_PL1_SIZE; e++)
+                if (ptab[t * ZJ_PT_ENTRIES + e] & 0x80000000u) ptab[t * ZJ_PT_ENTRIES + e] = 0x80000000u;
+    }
+    const uint32_t nwords = 4096;
+    std::vector<uint32_t> stream(nwords + 64), bm1(nwords + 64), bm2(nwords + 64);
+    uint64_t x = seed * 2654435761u + 99991u;
+    auto rnd = [&]() { x ^= x >> 12; x ^= x << 25; x ^= x >> 27; return (uint32_t)((x * 2685821657736338717ull) >> 32); };
+    ZjSel sel = {6, 0x30, 0x30};
+    const uint32_t selw = zj_selword(sel);
+    int bad = 0;
+    uint32_t steps1 = 0, steps2 = 0;
+    for (uint32_t it = 0; it < ntests; it++) {
+        for (auto &w : stream) w = (it & 1u) ? rnd() : (rnd() & rnd()); // dense, and sparse in ones (short codes)
+        std::fill(bm1.begin(), bm1.end(), 0u);
+        std::fill(bm2.begin(), bm2.end(), 0u);
+        ZjState a = {rnd() % 1000u, rnd() % 6u, rnd() % 64u}, b = a;
+        const uint32_t stop = a.p + 1u + rnd() % (nwords * 32u - 2000u);
+        // in stretches, as the kernels walk window by window
+        while (a.p < stop) {
+            const uint32_t part = std::min(stop, (a.p / 512u + 1u) * 512u);
+            {
+                ZjBits bits; bits.init(stream.data(), a.p);
+                ZjEmitWords em = {bm1.data()};
+                zj_decode_run<ZjBits, ZjEmitWords>(bits, wtbl.data(), canon, selw, sel.bpm, a, part, em);
+            }
+            {
+                ZjBits bits; bits.init(stream.data(), b.p);
+                ZjEmitWords em = {bm2.data()};
+                zj_decode_run_pairs<ZjBits, ZjEmitWords>(bits, ptab.data(), canon, selw, sel.bpm, b, part, em);
+            }
+            if (a.p != b.p || a.b != b.b || a.z != b.z) { bad++; break; }
+        }
+        if (bm1 != bm2) bad++;
+        (void)steps1; (void)steps2;
+    }
+    if (pairs_taken) {
+        uint32_t n = 0;
+        for (uint32_t t = 2; t < 4; t++)
+            for (uint32_t e = 0; e < (uint32_t)ZJ_PL1_SIZE; e++) {
+                const uint32_t v = ptab[t * ZJ_PT_ENTRIES + e];
+                if (!(v & 0x80000000u) && ((v >> 6) & 63u) != (v & 63u)) n++;
+            }
+        *pairs_taken = n;
+    }
+    return bad;
+}

@@ -247,3 +247,49 @@ def test_lookup_tables_equal_canonical_search():
     for h in tables:
         for cap in (256, 64, 0):
             assert S.zjsim_lookup_check(C.byref(h), cap, 20000, 5) == 0
+
+
+def test_pair_entries_walk_like_single_symbols():
+    """The sync pass looks up to two symbols at a time (pair entries).  On random bit streams, from random states,
+    window by window, that walk must stop in the same states and mark the same block starts as the
+    symbol-by-symbol walk: the fixtures' tables (test-baseline.jpg has single-code tables), the synthetic
+    generator's tables, random prefix codes, and every table without its second level (canonical search)."""
+    S = sim()
+    S.zjsim_pair_walk_check.argtypes = [C.POINTER(B.zj_huff), C.POINTER(B.zj_huff), C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32)]
+    S.zjsim_pair_walk_check.restype = C.c_int
+    pairs = []
+    files = [fixture_bytes(n) for n in ("porsche.jpg", "profile.jpg", "test-baseline.jpg", "out.jpg")] + [synth.encode(64, 64, 2, 2, seed=1)]
+    for data in files:
+        p = J.ParsedImage(data)
+        for tid in range(2):
+            if not (p.image.ht[tid][0] and p.image.ht[tid][1]):
+                continue
+            ac, dc = B.zj_huff(), B.zj_huff()
+            C.memmove(C.byref(ac), p.image.ht[tid][0], C.sizeof(ac))
+            C.memmove(C.byref(dc), p.image.ht[tid][1], C.sizeof(dc))
+            for cap in (256, 0):
+                n = C.c_uint32()
+                assert S.zjsim_pair_walk_check(C.byref(dc), C.byref(ac), cap, 300, 7 + tid, C.byref(n)) == 0
+                pairs.append(n.value)
+    assert max(pairs) > 300  # the tables of real files do hold pairs: most 10-bit windows begin with two short AC codes
+    rng = np.random.default_rng(12)
+    for _ in range(25):
+        hs = []
+        for _t in range(2):
+            counts, budget, nsym = [0] * 16, 1 << 16, 0
+            for l in range(1, 17):
+                unit = 1 << (16 - l)
+                c = min(budget // unit, 256 - nsym, int(rng.integers(0, 3 + l)) if l < 14 else int(rng.integers(0, 120)))
+                counts[l - 1] = c
+                budget -= c * unit
+                nsym += c
+            h = B.zj_huff()
+            for i in range(16):
+                h.counts[i] = counts[i]
+            for i, v in enumerate(rng.permutation(256)[:nsym]):
+                h.symbols[i] = int(v)
+            hs.append((h, nsym))
+        if min(n for _, n in hs) == 0:
+            continue
+        for cap in (256, 0):
+            assert S.zjsim_pair_walk_check(C.byref(hs[0][0]), C.byref(hs[1][0]), cap, 100, 3, None) == 0

@@ -1135,23 +1135,23 @@ __device__ __forceinline__ constexpr uint32_t zj_cos_bits(int n, int k)
 }
 
 // src/dct.rs:87-99: out[n] = 0.5 * fma(in7, C[n][7], ... fma(in0, C[n][0], 0.0)), ascending k.
-// Outputs n and 7 - n are computed together, two to an instruction (v_pk_fma_f32): each half is the same
-// IEEE fused multiply-add, in the same order, as the scalar chain.  C[7-n][k] = (-1)^k C[n][k], so the
-// two coefficients of a step differ at most in sign.
+// Outputs n and n + 1 are computed together, two to an instruction (v_pk_fma_f32): each half is the same
+// IEEE fused multiply-add, in the same order, as the scalar chain.  Neighbouring outputs share a register
+// pair, which is how the colour stage wants its pixels (pairing n with 7 - n cost a re-pairing move per value).
 typedef float zj_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void zj_idct_1d(const float (&in)[8], float (&out)[8])
 {
 #pragma unroll
-    for (int n = 0; n < 4; n++) {
+    for (int n = 0; n < 8; n += 2) {
         zj_f32x2 s = {0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const zj_f32x2 c = {__uint_as_float(zj_cos_bits(n, k)), __uint_as_float(zj_cos_bits(7 - n, k))};
+            const zj_f32x2 c = {__uint_as_float(zj_cos_bits(n, k)), __uint_as_float(zj_cos_bits(n + 1, k))};
             s = __builtin_elementwise_fma(zj_f32x2{in[k], in[k]}, c, s);
         }
         s = s * zj_f32x2{0.5f, 0.5f};
         out[n] = s.x;
-        out[7 - n] = s.y;
+        out[n + 1] = s.y;
     }
 }
 

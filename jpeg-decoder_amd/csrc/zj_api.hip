@@ -730,6 +730,10 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
         b->ready_valid = ok;
         if (ok) ok = hip_ok(ctx, hipEventRecord(b->ready, b->up), "event record");
     }
+    // The tables above were copied out of vectors that die with this call.  Copies from pageable memory are
+    // staged before hipMemcpyAsync returns on this runtime, but nothing here depends on that: wait for the
+    // upload stream (the decode stream, which may be busy with another batch of the workspace, is not touched).
+    if (ok) ok = hip_ok(ctx, hipStreamSynchronize(b->up), "sync after plan upload");
     if (!ok) { zj_batch_destroy(b); return nullptr; }
     b->L.nseg = (uint32_t)b->segs.size();
     b->L.nchunks = P.nchunks;

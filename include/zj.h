@@ -151,6 +151,17 @@ const char *zj_last_error(zj_ctx *ctx);
 zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *imgs, size_t n, uint32_t flags);
 void zj_batch_destroy(zj_batch *b);
 
+/* As zj_batch_create, with a window of MCU rows per image: coefficients and pixels are produced for MCU rows
+ * [row0[i], row0[i] + nrows[i]) only (nrows[i] == 0, or NULL arrays: the whole image); rgb[i] of the decode call
+ * then begins at the window's first pixel row.  The entropy front -- unstuffing, synchronisation, block positions,
+ * DC prediction -- still runs over the whole image: in a stream without restart markers nothing says where a row
+ * begins or what its predictors are until everything before it has been walked (the serial chain of
+ * src/decoder.rs:376-389).  This is how such an image is spread over several GPUs: every rank repeats the front
+ * (about a third of the work) and takes its band of rows of the rest, and the bands are gathered like those of a
+ * restart-marked image.  Coefficients outside the window are not produced (zj_batch_export_coef returns the
+ * arena as is there). */
+zj_batch *zj_batch_create_rows(zj_ctx *ctx, const zj_image *imgs, size_t n, uint32_t flags, const uint32_t *row0, const uint32_t *nrows);
+
 /* ---- workspaces: device memory shared by batches that are decoded one after the other ----
  * A batch made by zj_batch_create owns every byte it uses, the coefficient arena (128 bytes per block)
  * included, so a job too large for one batch would have to allocate and free per sub-batch.  A workspace

@@ -59,7 +59,7 @@ _EXPORTS = [
     "zj_batch_segments",
     "zj_decode_batch",
     "zj_workspace_estimate", "zj_workspace_create", "zj_workspace_destroy", "zj_batch_create_in", "zj_batch_memory",
-    "zj_batch_counters",
+    "zj_batch_counters", "zj_batch_create_rows",
     "zj_decode_batch_noalloc",
 ]
 
@@ -107,6 +107,7 @@ def lib():
     L.zj_workspace_destroy.argtypes = [vp]; L.zj_workspace_destroy.restype = None
     L.zj_batch_create_in.argtypes = [vp, C.c_uint32, C.POINTER(zj_image), sz, C.c_uint32]; L.zj_batch_create_in.restype = vp
     L.zj_batch_memory.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]; L.zj_batch_memory.restype = C.c_int
+    L.zj_batch_create_rows.argtypes = [vp, C.POINTER(zj_image), sz, C.c_uint32, u32p, u32p]; L.zj_batch_create_rows.restype = vp
     L.zj_batch_counters.argtypes = [vp, u32p]; L.zj_batch_counters.restype = C.c_int
     L.zj_decode_batch_noalloc.argtypes = [vp, C.POINTER(zj_image), sz, C.POINTER(vp), C.POINTER(sz), u32p]; L.zj_decode_batch_noalloc.restype = C.c_int
     _lib = L

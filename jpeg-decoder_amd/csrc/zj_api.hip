@@ -343,7 +343,7 @@ enum { ZJ_ALLOC_OWN = 0, ZJ_ALLOC_WORKSPACE, ZJ_ALLOC_NONE };
 // The planner behind zj_batch_create, zj_batch_create_in and zj_decode_batch_noalloc.
 // ZJ_ALLOC_NONE: plan and scratch memory both come out of the range [fixed_base, fixed_base + fixed_cap).
 static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n, uint32_t flags, int mode, zj_workspace *ws, uint32_t slot,
-                                   uint8_t *fixed_base, size_t fixed_cap)
+                                   uint8_t *fixed_base, size_t fixed_cap, const uint32_t *win_row0 = nullptr, const uint32_t *win_nrows = nullptr)
 {
     if (!ctx) return nullptr;
     ctx->err_code = ZJ_E_INVALID;
@@ -470,6 +470,20 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
         d.mcuy = (d.h + 8 * d.vs - 1) / (8 * d.vs);
         const uint64_t nmcu = (uint64_t)d.mcux * d.mcuy;
         d.nblocks = (uint32_t)(nmcu * d.bpm);
+        // the MCU rows that are wanted (zj_batch_create_rows); by default all of them
+        d.row0 = 0;
+        d.nrows = d.mcuy;
+        if (win_row0 && win_nrows && win_nrows[i]) {
+            if (win_row0[i] >= d.mcuy || win_nrows[i] > d.mcuy - win_row0[i]) {
+                ctx->err = "rows outside the image";
+                ctx->err_code = ZJ_E_INVALID;
+                zj_batch_destroy(b);
+                return nullptr;
+            }
+            d.row0 = win_row0[i];
+            d.nrows = win_nrows[i];
+        }
+        const uint64_t wmcu = (uint64_t)d.mcux * d.nrows; // MCUs of those rows
         for (uint32_t k = 0; k < d.bpm; k++) {
             const uint32_t c = k < d.hs * d.vs ? 0u : (k == d.hs * d.vs ? 1u : 2u);
             d.compsel |= c << (2 * k);
@@ -615,18 +629,19 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
             d.k1w_mcus = (d.hs * d.vs == 1 ? 64u : 32u) * k1w_mult;
             const uint32_t per_wg = 4u * d.k1w_mcus; // MCUs per write-pass workgroup
             d.first_k1w = (uint32_t)k1w_img.size();
-            for (uint64_t m = 0; m < nmcu; m += per_wg) k1w_img.push_back((uint32_t)i);
+            for (uint64_t m = 0; m < wmcu; m += per_wg) k1w_img.push_back((uint32_t)i);
         }
         const uint32_t T = ncomp == 1 ? 96u : 4u * zj_k2_wave_mcus(d.hs, d.vs); // MCUs per strip of stage 2
         d.strips_x = (d.mcux + T - 1) / T;
-        const uint32_t ns = (d.strips_x * d.mcuy + k2_ns - 1) / k2_ns; // workgroups of stage 2
+        const uint32_t ns = (d.strips_x * d.nrows + k2_ns - 1) / k2_ns; // workgroups of stage 2
         const int cls = ncomp == 1 ? 4 : (d.hs == 2 && d.vs == 2) ? 0 : (d.hs == 1 && d.vs == 1) ? 1 : (d.hs == 2) ? 2 : 3;
         for (uint32_t s = 0; s < ns; s++) { k2_grp[cls].push_back(s); k2_img[cls].push_back((uint32_t)i); }
         nstrip_total += ns;
         b->scan_bytes += im.scan_len;
-        b->coef_bytes += (uint64_t)d.nblocks * 128;
-        b->rgb_bytes += (uint64_t)d.w * d.h * 3;
-        b->pixels += (uint64_t)d.w * d.h;
+        b->coef_bytes += wmcu * d.bpm * 128;
+        const uint32_t mh = 8u * d.vs, wy0 = d.row0 * mh, wh = std::min<uint32_t>(d.nrows * mh, d.h - wy0); // pixel rows produced
+        b->rgb_bytes += (uint64_t)d.w * wh * 3;
+        b->pixels += (uint64_t)d.w * wh;
         if (nsub_total > 0xF0000000ull || nblk_total > 0xF0000000ull || nwin_total > 0xF0000000ull || ust_total > 0xF0000000ull) {
             ctx->err = "batch too large for 32-bit indices";
             ctx->err_code = ZJ_E_INVALID;
@@ -751,6 +766,11 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
 extern "C" zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *images, size_t n, uint32_t flags)
 {
     return batch_create_impl(ctx, images, n, flags, ZJ_ALLOC_OWN, nullptr, 0, nullptr, 0);
+}
+
+extern "C" zj_batch *zj_batch_create_rows(zj_ctx *ctx, const zj_image *images, size_t n, uint32_t flags, const uint32_t *row0, const uint32_t *nrows)
+{
+    return batch_create_impl(ctx, images, n, flags, ZJ_ALLOC_OWN, nullptr, 0, nullptr, 0, row0, nrows);
 }
 
 // ---------------------------------------------------------------------------------- workspaces

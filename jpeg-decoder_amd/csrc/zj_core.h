@@ -91,6 +91,8 @@ struct ZjImgDev {
                             // bit 2: so do its pair tables
     uint32_t first_k1w;     // first workgroup of the write pass
     uint32_t k1w_mcus;      // MCUs per wavefront of the write pass (a multiple of 64)
+    uint32_t row0, nrows;   // MCU rows whose coefficients and pixels are produced (the entropy front always covers the
+                            // whole image); the pixel buffer begins at MCU row row0
 };
 
 struct ZjSegDev {

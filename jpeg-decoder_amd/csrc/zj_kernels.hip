@@ -928,8 +928,8 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
     const uint32_t nl = im.hs * im.vs, bpm = im.bpm;
     const uint32_t shl = nl == 4u ? 2u : (nl == 2u ? 1u : 0u);     // log2 of the luma blocks per MCU
     const uint32_t M = im.k1w_mcus;                                // MCUs per wavefront
-    const uint32_t m0 = ((blockIdx.x - im.first_k1w) * 4u + wave) * M; // first MCU of this wavefront
-    const uint32_t nmcu = im.nblocks / bpm;
+    const uint32_t m0 = im.row0 * im.mcux + ((blockIdx.x - im.first_k1w) * 4u + wave) * M; // first MCU of this wavefront
+    const uint32_t nmcu = min(im.nblocks / bpm, (im.row0 + im.nrows) * im.mcux); // end of the rows that are wanted
     if (m0 >= nmcu) return; // wave-uniform
     const uint32_t rounds_l = (M << shl) / 64u, rounds = rounds_l + M * (bpm - nl) / 64u; // no chroma rounds for one component
     uint32_t *row32 = &tile[wave][lane * 33u];
@@ -1252,7 +1252,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
     constexpr int PIECES = ROWB / 16;
     // the few descriptor fields of the loop, read once (through the reference they would be read again,
     // and waited for, after every store)
-    const uint32_t im_first_block = im.first_block, im_h = im.h, im_mcux = im.mcux, im_strips_x = im.strips_x, im_w = im.w;
+    const uint32_t im_first_block = im.first_block, im_h = im.h, im_mcux = im.mcux, im_strips_x = im.strips_x, im_w = im.w, im_row0 = im.row0;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float *blk = blk_all + wave * (WB * ZJ_K2_BSTRIDE);
     uint8_t *rgb = P.rgb[ii];
@@ -1271,7 +1271,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
     const uint4 *qpart = reinterpret_cast<const uint4 *>(qlds) + part;
 
     auto strip_src = [&](uint32_t strip, uint32_t &nbw) -> const int16_t * {
-        const uint32_t my = strip / im_strips_x, sx = strip % im_strips_x;
+        const uint32_t my = im_row0 + strip / im_strips_x, sx = strip % im_strips_x;
         const uint32_t x0 = sx * T + wave * TW; // first MCU of this wavefront
         const uint32_t nm = x0 < im_mcux ? min((uint32_t)TW, im_mcux - x0) : 0u;
         nbw = nm * BPM;
@@ -1293,7 +1293,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
         load3(src, nbw, v);
     }
     for (uint32_t strip = strip0; strip < strip1; strip++) {
-        const uint32_t my = strip / im_strips_x, sx = strip % im_strips_x;
+        const uint32_t my = im_row0 + strip / im_strips_x, sx = strip % im_strips_x;
         const uint32_t x0 = sx * T + wave * TW;
         // phase 1: dequantise (i16 wrapping, both operands in zig-zag order, src/decoder.rs:179-184) two
         // coefficients per instruction, de-zigzag into LDS as f32 (exact), src/decoder.rs:296-300
@@ -1417,7 +1417,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
             const uint32_t r = q / PIECES, pc = q % PIECES;
             const uint32_t o = pc * 16u;
             if (r >= rows_valid || o >= row_valid) continue;
-            uint8_t *dst = rgb + (size_t)(my * MH + r) * stride + xb + o;
+            uint8_t *dst = rgb + (size_t)((my - im_row0) * MH + r) * stride + xb + o;
             const uint4 pv = *reinterpret_cast<const uint4 *>(stage + r * ROWP + o);
             if (vec_ok && o + 16u <= row_valid) {
                 zj_store_global16(dst, pv);
@@ -1443,7 +1443,7 @@ __global__ __launch_bounds__(256) void zj_k2_idct_rgb(ZjParams P, uint32_t first
     const ZjImgDev &im = P.imgs[ii]; // a reference on purpose: a copy costs this kernel registers and with them a wavefront per SIMD
     if (threadIdx.x < 192u) qlds[threadIdx.x] = P.qts[im.qt_off[threadIdx.x >> 6] + (threadIdx.x & 63u)];
     __syncthreads();
-    const uint32_t nstrips = im.strips_x * im.mcuy;
+    const uint32_t nstrips = im.strips_x * im.nrows;
     const uint32_t s0 = grp * P.k2_ns;
     const uint32_t s1 = min(s0 + P.k2_ns, nstrips);
     zj_k2_body<HS, VS>(P, im, ii, s0, s1, blk, qlds);
@@ -1478,10 +1478,10 @@ __global__ __launch_bounds__(256) void zj_k2_idct_gray(ZjParams P, uint32_t firs
     }
     const uint4 qv = reinterpret_cast<const uint4 *>(qlds)[part];
     const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w};
-    const uint32_t nstrips = im.strips_x * im.mcuy;
+    const uint32_t nstrips = im.strips_x * im.nrows;
     const uint32_t s0 = grp * P.k2_ns, s1 = min(s0 + P.k2_ns, nstrips);
     for (uint32_t strip = s0; strip < s1; strip++) {
-        const uint32_t my = strip / im.strips_x, sx = strip % im.strips_x;
+        const uint32_t my = im.row0 + strip / im.strips_x, sx = strip % im.strips_x;
         const uint32_t x0 = sx * T + wave * TW; // first block of this wavefront in the block row
         const uint32_t nbw = x0 < im.mcux ? min((uint32_t)TW, im.mcux - x0) : 0u;
         const int16_t *src = P.qcoef + ((size_t)im.first_block + (size_t)my * im.mcux + x0) * 64u;
@@ -1552,7 +1552,7 @@ __global__ __launch_bounds__(256) void zj_k2_idct_gray(ZjParams P, uint32_t firs
         for (uint32_t q = lane; q < (uint32_t)(PIECES * 8); q += 64u) {
             const uint32_t r = q / PIECES, o = (q % PIECES) * 16u;
             if (r >= rows_valid || o >= row_valid) continue;
-            uint8_t *dst = rgb + (size_t)(my * 8u + r) * stride + xb + o;
+            uint8_t *dst = rgb + (size_t)((my - im.row0) * 8u + r) * stride + xb + o;
             const uint4 pv = *reinterpret_cast<const uint4 *>(stage + r * ROWP + o);
             if (vec_ok && o + 16u <= row_valid) {
                 *reinterpret_cast<uint4 *>(dst) = pv;

@@ -174,7 +174,7 @@ class Batch:
     """A planned batch of parsed images, resident on the GPU (zj_batch_create, or zj_batch_create_in
     when a workspace and one of its plan slots are given)."""
 
-    def __init__(self, ctx: Context, images, subseq_bits=0, workspace=None, slot=0):
+    def __init__(self, ctx: Context, images, subseq_bits=0, workspace=None, slot=0, rows=None):
         self.ctx = ctx
         self.images = list(images)
         n = len(self.images)
@@ -182,7 +182,14 @@ class Batch:
         arr = image_array(self.images)
         self._arr = arr
         self.workspace = workspace
-        if workspace is None:
+        self.rows = rows  # per image (first MCU row, MCU rows) of the output window, or None
+        if rows is not None:
+            if workspace is not None:
+                raise DecodeError("device", "row windows and workspaces are separate entry points")
+            r0 = (C.c_uint32 * max(n, 1))(*[r[0] if r else 0 for r in rows])
+            nr = (C.c_uint32 * max(n, 1))(*[r[1] if r else 0 for r in rows])
+            self.h = B.lib().zj_batch_create_rows(ctx.h, arr, n, subseq_bits, r0, nr)
+        elif workspace is None:
             self.h = B.lib().zj_batch_create(ctx.h, arr, n, subseq_bits)
         else:
             self.h = B.lib().zj_batch_create_in(workspace.h, slot, arr, n, subseq_bits)
@@ -194,10 +201,18 @@ class Batch:
         """Device output buffers (torch uint8 tensors, rows padded to 16 bytes)."""
         torch = self.ctx._torch
         outs = []
-        for im in self.images:
+        for i, im in enumerate(self.images):
             stride = (im.width * 3 + 15) // 16 * 16
-            outs.append(torch.empty((im.height, stride), dtype=torch.uint8, device=f"cuda:{self.ctx.device}"))
+            outs.append(torch.empty((self.window_height(i), stride), dtype=torch.uint8, device=f"cuda:{self.ctx.device}"))
         return outs
+
+    def window_height(self, i):
+        """Pixel rows image i produces: all of them, or those of its window of MCU rows."""
+        im = self.images[i]
+        if not self.rows or not self.rows[i] or not self.rows[i][1]:
+            return im.height
+        mh = 8 * max(im.image.vsamp[0], 1)
+        return min(self.rows[i][1] * mh, im.height - self.rows[i][0] * mh)
 
     def decode(self, rgb_tensors=None):
         """Launch the hot path (asynchronous).  rgb_tensors: list of 2-D uint8 CUDA tensors or None."""
@@ -207,7 +222,7 @@ class Batch:
         if rgb_tensors is not None:
             for i, t in enumerate(rgb_tensors):
                 if t is not None:
-                    check_output_tensor(t, self.images[i], self.ctx.device)
+                    check_output_tensor(t, self.images[i], self.ctx.device, self.window_height(i))
                     ptrs[i] = t.data_ptr()
                     strides[i] = t.stride(0)
         self._rgb = rgb_tensors
@@ -283,7 +298,7 @@ class Batch:
             pass
 
 
-def check_output_tensor(t, im, device):
+def check_output_tensor(t, im, device, height=None):
     """A pixel output must be a 2-D uint8 tensor on the context's GPU with unit inner stride, at least
     `height` rows and a row pitch of at least 3 * width bytes: the kernels write exactly that region."""
     if str(t.dtype) != "torch.uint8":
@@ -292,7 +307,8 @@ def check_output_tensor(t, im, device):
         raise DecodeError("device", f"output tensor must be 2-D on cuda:{device}")
     if t.shape[1] > 1 and t.stride(1) != 1:
         raise DecodeError("device", "output tensor rows must be contiguous")
-    if t.shape[0] < im.height or t.shape[1] < 3 * im.width or (im.height > 1 and t.stride(0) < 3 * im.width):
+    height = im.height if height is None else height
+    if t.shape[0] < height or t.shape[1] < 3 * im.width or (height > 1 and t.stride(0) < 3 * im.width):
         raise DecodeError("device", f"output tensor {tuple(t.shape)} (pitch {t.stride(0)}) is too small for {im.width}x{im.height} RGB")
 
 

@@ -136,3 +136,55 @@ def test_command_line_driver_writes_the_reference_output(tmp_path):
     bad.write_bytes(b"not a jpeg")
     r = subprocess.run([exe, str(bad)], cwd=tmp_path, capture_output=True, text=True, timeout=100)
     assert r.returncode != 0 and "decode failed" in r.stderr
+
+
+def test_rows_of_images_without_restart_markers(ctx):
+    """An image without restart markers spread over several ranks: every rank repeats the entropy front over the
+    whole stream and produces the coefficients and pixels of its band of MCU rows only (zj_batch_create_rows).  The
+    bands of 1 to 5 ranks must tile the oracle's image, the coefficients inside a band must be the oracle's, and rows
+    outside the image are refused.  large.jpg is the reference's restart-free 7680x4320 file; the others cover 4:2:0
+    with a height that is no multiple of the MCU height, one-component frames, and a mixed batch with windows on
+    some images only."""
+    import torch
+    cases = [("large.jpg", fixture_bytes("large.jpg")), ("out.jpg", fixture_bytes("out.jpg")),
+             ("gray", synth.encode(333, 211, 0, 0, 90, 0, 81, 0)), ("422", synth.encode(640, 200, 2, 1, 90, 2, 82, 0))]
+    for name, data in cases:
+        p = J.ParsedImage(data)
+        ref = oracle.decode(data)
+        hs, vs = (p.image.hsamp[0], p.image.vsamp[0])
+        mcux, mcuy, _, mh = shard.mcu_geometry(p.width, p.height, hs, vs)
+        bpm = 1 if p.image.ncomp == 1 else hs * vs + 2
+        for world in ((1, 3) if name == "large.jpg" else (1, 2, 5)):
+            per = (mcuy + world - 1) // world
+            bands = [(r0, min(per, mcuy - r0)) for r0 in range(0, mcuy, per)]
+            got = []
+            for (r0, n) in bands:
+                b = J.Batch(ctx, [p], rows=[(r0, n)])
+                outs = b.alloc_rgb()
+                assert outs[0].shape[0] == min(n * mh, p.height - r0 * mh)
+                b.decode(outs)
+                assert not b.finish().any()
+                got.append(outs[0][:, : p.width * 3].reshape(-1, p.width, 3).cpu().numpy())
+                q = b.coefficients(0)
+                lo, hi = r0 * mcux * bpm, (r0 + n) * mcux * bpm
+                assert np.array_equal(q[lo:hi], ref.qcoef[lo:hi]), (name, world, r0)
+                b.close()
+            assert np.array_equal(np.concatenate(got, 0), ref.rgb), (name, world)
+        with pytest.raises(J.DecodeError):
+            J.Batch(ctx, [p], rows=[(mcuy, 1)])
+        with pytest.raises(J.DecodeError):
+            J.Batch(ctx, [p], rows=[(1, mcuy)])
+    # a batch where only some images have a window
+    files = [c[1] for c in cases[1:]] + [synth.encode(200, 120, 2, 2, 90, 0, 83, 4)]
+    imgs = [J.ParsedImage(f) for f in files]
+    rows = [(3, 10), None, (0, 0), (2, 3)]
+    b = J.Batch(ctx, imgs, rows=rows)
+    outs = b.alloc_rgb()
+    b.decode(outs)
+    assert not b.finish().any()
+    for f, im, o, r, i in zip(files, imgs, outs, rows, range(4)):
+        ref = oracle.decode(f).rgb
+        mh = 8 * im.image.vsamp[0]
+        y0 = r[0] * mh if r and r[1] else 0
+        assert np.array_equal(o[:, : im.width * 3].reshape(-1, im.width, 3).cpu().numpy(), ref[y0: y0 + b.window_height(i)]), i
+    b.close()

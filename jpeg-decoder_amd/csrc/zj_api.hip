@@ -398,7 +398,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
 
     b->imgs.resize(n);
     b->unsupported.assign(n, 0);
-    std::vector<uint32_t> chunk_seg, blk256_img, k1w_img, ptile_seg, tile_seg, dtile_seg;
+    std::vector<uint32_t> chunk_seg, blk256_img, k1w_img, ptile_seg, tile_seg, small_seg, dtile_seg;
     uint64_t nwin_total = 0;
     std::vector<uint32_t> k2_grp[ZJ_K2_CLASSES], k2_img[ZJ_K2_CLASSES]; // stage-2 workgroups per sampling layout
     std::vector<uint16_t> luts;
@@ -604,10 +604,15 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
                 sub_in_img += s.lanes;
                 open_used += s.lanes;
             }
-            s.first_tile = (uint32_t)tile_seg.size();
-            s.ntiles = (uint32_t)((s.raw_end - (s.raw_begin & ~15ull) + ZJ_UNSTUFF_TILE - 1u) / ZJ_UNSTUFF_TILE);
-            if (s.ntiles == 0) s.ntiles = 1; // an empty segment still publishes its payload length
-            for (uint32_t t = 0; t < s.ntiles; t++) tile_seg.push_back((uint32_t)b->segs.size());
+            if (s.raw_end - (s.raw_begin & ~15ull) <= ZJ_UNSTUFF_SMALL) { // also an empty segment, which still publishes its payload length
+                s.first_tile = 0;
+                s.ntiles = 1;
+                small_seg.push_back((uint32_t)b->segs.size());
+            } else {
+                s.first_tile = (uint32_t)tile_seg.size();
+                s.ntiles = (uint32_t)((s.raw_end - (s.raw_begin & ~15ull) + ZJ_UNSTUFF_TILE - 1u) / ZJ_UNSTUFF_TILE);
+                for (uint32_t t = 0; t < s.ntiles; t++) tile_seg.push_back((uint32_t)b->segs.size());
+            }
             s.first_ptile = (uint32_t)ptile_seg.size();
             for (uint64_t w = 0; w < (uint64_t)s.nsub * s.nc; w += 256u) ptile_seg.push_back((uint32_t)b->segs.size());
             const uint64_t m0 = ri ? k * ri : 0;
@@ -658,6 +663,8 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     P.blk256_img = dev_upload(b, blk256_img);
     P.k1w_img = dev_upload(b, k1w_img);
     P.ptile_seg = dev_upload(b, ptile_seg);
+    const size_t nbig = tile_seg.size(); // tiles of the 128-thread form; the short segments' entries follow them
+    tile_seg.insert(tile_seg.end(), small_seg.begin(), small_seg.end());
     P.tile_seg = dev_upload(b, tile_seg);
     P.dtile_seg = dev_upload(b, dtile_seg);
     std::vector<uint32_t> strip_grp_all, strip_img_all;
@@ -707,8 +714,8 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     if (ok) {
         const int S = ZJ_MEM_SCRATCH;
         P.dtile_sum = dev_alloc<uint32_t>(b, dtile_seg.size() * 4, true, S);
-        P.tile_status = dev_alloc<uint64_t>(b, tile_seg.size() + (b->segs.size() + 1) / 2 + 1, true, S);
-        P.seg_ticket = P.tile_status ? reinterpret_cast<uint32_t *>(P.tile_status + tile_seg.size()) : nullptr;
+        P.tile_status = dev_alloc<uint64_t>(b, nbig + (b->segs.size() + 1) / 2 + 1, true, S);
+        P.seg_ticket = P.tile_status ? reinterpret_cast<uint32_t *>(P.tile_status + nbig) : nullptr;
         P.ust = dev_alloc<uint8_t>(b, ust_total + 1040, true, S);
         P.seg_payload_bits = dev_alloc<uint32_t>(b, b->segs.size(), true, S);
         P.seg_found = dev_alloc<uint32_t>(b, b->segs.size(), true, S);
@@ -755,7 +762,8 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     b->L.nblk256 = (uint32_t)blk256_img.size();
     b->L.nk1w = (uint32_t)k1w_img.size();
     b->L.nptiles = (uint32_t)ptile_seg.size();
-    b->L.ntiles = (uint32_t)tile_seg.size();
+    b->L.ntiles = (uint32_t)nbig;
+    b->L.nsmall = (uint32_t)small_seg.size();
     b->L.ndtiles = (uint32_t)dtile_seg.size();
     b->L.nstrips = (uint32_t)strip_grp_all.size();
     b->L.fix_iters = 1;

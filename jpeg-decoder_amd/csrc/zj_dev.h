@@ -32,7 +32,7 @@ struct ZjParams {
     const uint32_t *ptile_seg;  // [position-pass workgroup] segment
     const uint32_t *dtile_seg;  // [DC-scan tile of 256 MCUs] segment
     uint32_t *dtile_sum;        // [DC-scan tile][4] per component: sum of the tile's differences, then of the tiles before it
-    const uint32_t *tile_seg;   // [unstuff tile] segment
+    const uint32_t *tile_seg;   // [unstuff tile] segment; behind the tiles, the segments short enough for one small tile each
     uint64_t *tile_status;      // [unstuff tile] look-back word: flag << 32 | bytes
     uint32_t *seg_ticket;       // [segment] next tile of the segment to hand out (stored behind tile_status)
     uint32_t *blockpos;         // [block] bit position of the block in its segment's stream
@@ -63,9 +63,11 @@ struct ZjParams {
 __host__ __device__ constexpr uint32_t zj_k2_wave_mcus(uint32_t hs, uint32_t vs) { return vs == 2u ? 4u : 8u; }
 #define ZJ_K2_CLASSES 5
 #define ZJ_UNSTUFF_TILE 15872u // raw bytes per workgroup of the unstuff pass: 128 threads x 31 words
+#define ZJ_UNSTUFF_SMALL 3840u // and of its one-wavefront form for segments that fit into one such tile: 64 threads x 15 words
 
 struct ZjLaunch {
     uint32_t nseg, nchunks, nblk256, nstrips, nk1w, nptiles, ntiles, ndtiles;
+    uint32_t nsmall;  // segments unstuffed by the one-wavefront form; their entries of tile_seg follow the `ntiles` others
     uint32_t npacked; // chunks shared by several short segments (the packed form of the sync kernel)
     uint32_t k2_first[ZJ_K2_CLASSES], k2_count[ZJ_K2_CLASSES]; // stage-2 workgroups per layout (2x2, 1x1, 2x1, 1x2, one component)
     int fix_iters;

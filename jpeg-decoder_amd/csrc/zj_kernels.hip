@@ -221,16 +221,19 @@ __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *str
 // and the 64 lanes of a wavefront that read or write word j of their runs touch every LDS bank twice.
 // The unstuffed arena starts zeroed and the same bytes are written on every decode of a batch, so the
 // bytes behind a segment's payload stay zero (the reference pads with zeros, src/bitstream.rs:80-84).
-#define ZJ_K0_THREADS 128
-#define ZJ_K0_WORDS 31u
-#define ZJ_K0_TILE ((uint32_t)ZJ_K0_THREADS * ZJ_K0_WORDS * 4u) // must equal the tile size the batch planner uses
-static_assert(ZJ_K0_TILE == ZJ_UNSTUFF_TILE, "tile size of the unstuff pass");
+// Segments that fit into 3.75 KiB of raw bytes -- short restart intervals, of which an image can hold tens of
+// thousands -- take the SINGLE form: one wavefront per segment with a tile of that size (60 bytes per lane),
+// no ticket, no look-back and nothing published, so that a CU holds four times as many of them and each
+// has fewer dependent steps.
 #define ZJ_K0_PAD 16u // the compacted bytes begin here in the LDS buffer
 #define ZJ_TS_AGG (1ull << 32)
 #define ZJ_TS_INCL (2ull << 32)
 
-__global__ __launch_bounds__(ZJ_K0_THREADS) void zj_k0_unstuff(ZjParams P)
+template <uint32_t ZJ_K0_THREADS, uint32_t ZJ_K0_WORDS, bool SINGLE>
+__global__ __launch_bounds__(ZJ_K0_THREADS) void zj_k0_unstuff(ZjParams P, uint32_t tile0)
 {
+    constexpr uint32_t ZJ_K0_TILE = ZJ_K0_THREADS * ZJ_K0_WORDS * 4u; // must equal the tile size the batch planner uses
+    static_assert(ZJ_K0_TILE == (SINGLE ? ZJ_UNSTUFF_SMALL : ZJ_UNSTUFF_TILE), "tile size of the unstuff pass");
     __shared__ __attribute__((aligned(16))) uint8_t buf[ZJ_K0_TILE + ZJ_K0_PAD + 64]; // first the raw tile, then the compacted bytes
     __shared__ uint32_t wsum[8];
     __shared__ uint32_t s_tile, s_prefix;
@@ -238,11 +241,13 @@ __global__ __launch_bounds__(ZJ_K0_THREADS) void zj_k0_unstuff(ZjParams P)
     // The workgroup's segment is fixed by its index; which of the segment's tiles it takes is decided by a
     // ticket per segment (one counter for the whole grid would serialise a quarter of a million atomics
     // on one address).
-    const uint32_t s = P.tile_seg[blockIdx.x];
+    const uint32_t s = P.tile_seg[tile0 + blockIdx.x];
     const ZjSegDev sg = P.segs[s];
-    if (tid == 0) s_tile = atomicAdd(&P.seg_ticket[s], 1u);
-    __syncthreads();
-    const uint32_t tj = s_tile;
+    if (!SINGLE) {
+        if (tid == 0) s_tile = atomicAdd(&P.seg_ticket[s], 1u);
+        __syncthreads();
+    }
+    const uint32_t tj = SINGLE ? 0u : s_tile;
     const uint32_t tile = sg.first_tile + tj;
     const uint64_t a0 = sg.raw_begin & ~15ull;
     const uint64_t t0 = a0 + (uint64_t)tj * ZJ_K0_TILE;
@@ -275,13 +280,18 @@ __global__ __launch_bounds__(ZJ_K0_THREADS) void zj_k0_unstuff(ZjParams P)
         const uint64_t po = (uint64_t)tj * ZJ_K0_TILE + 16u * pc;
         const bool ok = nonempty && po <= lim;
         const uint4 v = make_uint4(ok ? ld[i].x : 0u, ok ? ld[i].y : 0u, ok ? ld[i].z : 0u, ok ? ld[i].w : 0u);
-        if (pc < NPC) reinterpret_cast<uint4 *>(buf)[pc] = v;
+        if (pc < NPC) reinterpret_cast<uint4 *>(buf)[pc] = v; // unconditional: a store under `ok` makes the compiler wait for each load in turn
     }
     uint32_t pf = has_before && pfb == 0xFFu; // is the byte before this thread's first byte an FF of the segment
     __syncthreads();
+    // A wavefront none of whose bytes belong to the segment (most of a tile, when restart intervals are
+    // short) only takes part in the barriers and the scan.
+    const bool wave_empty = __all(lo >= hi);
     uint32_t w[ZJ_K0_WORDS];
+    if (!wave_empty) {
 #pragma unroll
-    for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) w[j] = reinterpret_cast<const uint32_t *>(buf)[tid * ZJ_K0_WORDS + j];
+        for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) w[j] = reinterpret_cast<const uint32_t *>(buf)[tid * ZJ_K0_WORDS + j];
+    }
 
     // kill[j]: bit 7 of byte k set when byte 4j+k is not kept (a stuffed 00, or outside the segment)
     uint32_t kill[ZJ_K0_WORDS];
@@ -300,28 +310,33 @@ __global__ __launch_bounds__(ZJ_K0_THREADS) void zj_k0_unstuff(ZjParams P)
             fprev = f;
         }
         n = (uint32_t)NB - ndrop;
-    } else {
-        n = 0;
+    } else if (!wave_empty) {
+        // first and last tile of a segment: the same word-parallel tests, with the bytes outside [lo, hi)
+        // masked -- they are not kept, and an FF among them is not "the byte before"
+        uint32_t fprev = pf ? 0x80000000u : 0u, ndrop = 0;
 #pragma unroll
         for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) {
-            uint32_t kl = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; k++) {
-                const uint32_t byte = (w[j] >> (8u * k)) & 0xFFu;
-                const bool inr = 4u * j + k >= lo && 4u * j + k < hi;
-                const bool kept = inr && !((byte == 0u) && pf);
-                if (!kept) kl |= 0x80u << (8u * k);
-                n += kept ? 1u : 0u;
-                pf = inr && (byte == 0xFFu);
-            }
-            kill[j] = kl;
+            const int32_t lj = (int32_t)lo - (int32_t)(4u * j), hj = (int32_t)hi - (int32_t)(4u * j);
+            const uint32_t l4 = lj <= 0 ? 0u : (lj >= 4 ? 4u : (uint32_t)lj), h4 = hj <= 0 ? 0u : (hj >= 4 ? 4u : (uint32_t)hj);
+            const uint32_t ge = (uint32_t)(0x80808080ull << (8u * l4)), lt = 0x80808080u & ~(uint32_t)(0x80808080ull << (8u * h4));
+            const uint32_t inm = ge & lt; // bit 7 of every byte of the word that belongs to the segment
+            const uint32_t x = w[j], y = ~x;
+            const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+            const uint32_t f = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu) & inm;
+            const uint32_t before = __builtin_amdgcn_alignbyte(f, fprev, 3);
+            kill[j] = (z & before) | (inm ^ 0x80808080u);
+            ndrop += __popc(kill[j]);
+            fprev = f;
         }
+        n = (uint32_t)NB - ndrop;
+    } else {
+        n = 0;
     }
     uint32_t total;
     const uint32_t inc = block_incl_scan<ZJ_K0_THREADS / 64>(n, wsum, &total); // its barriers also end the reads of the raw tile
     // the tile's own count goes out first, so that the tiles behind it can already add it up
-    if (tid == 0 && tj > 0) __hip_atomic_store(&P.tile_status[tile], ZJ_TS_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    {
+    if (!SINGLE && tid == 0 && tj > 0) __hip_atomic_store(&P.tile_status[tile], ZJ_TS_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!wave_empty) {
         // Compaction in LDS, from byte ZJ_K0_PAD on, before the tile's place in the segment is known (the
         // wait for the predecessors is hidden behind it).  Every byte is stored at the position of the next
         // kept byte: a byte that is not kept is overwritten by the kept byte that follows it in the same
@@ -339,7 +354,9 @@ __global__ __launch_bounds__(ZJ_K0_THREADS) void zj_k0_unstuff(ZjParams P)
             }
         }
     }
-    if (tid < 64u) {
+    if (SINGLE) {
+        if (tid == 0) { s_prefix = 0; P.seg_payload_bits[s] = total * 8u; }
+    } else if (tid < 64u) {
         // look-back by the first wavefront: 64 predecessors per step.  The nearest tile that has published
         // an inclusive prefix ends the walk; every tile between it and this one must at least have
         // published its own count, otherwise the step is repeated.
@@ -402,7 +419,7 @@ __global__ __launch_bounds__(ZJ_K0_THREADS) void zj_k0_unstuff(ZjParams P)
     }
     // The segment's last tile clears the reserved bytes behind the payload: the readers run up to 96 bytes
     // past it and must find zeros there (src/bitstream.rs:80-84), whatever the arena held before.
-    if (tile + 1u == sg.first_tile + sg.ntiles) {
+    if (SINGLE || tile + 1u == sg.first_tile + sg.ntiles) {
         uint8_t *seg_out = P.ust + sg.out_off;
         for (uint32_t i = prefix + total + tid; i < sg.out_cap; i += ZJ_K0_THREADS) seg_out[i] = 0;
     }
@@ -1666,7 +1683,8 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     if (ev) hipEventRecord(ev[e++], st);
     hipMemsetAsync(P.flags, 0, 8, st); // words 2 and 3 count over the batch's life
     hipMemsetAsync(P.tile_status, 0, (size_t)L.ntiles * sizeof(uint64_t) + (size_t)L.nseg * sizeof(uint32_t), st); // look-back words and the tickets behind them
-    if (L.ntiles) hipLaunchKernelGGL(zj_k0_unstuff, dim3(L.ntiles), dim3(ZJ_K0_THREADS), 0, st, P);
+    if (L.ntiles) hipLaunchKernelGGL((zj_k0_unstuff<128, 31, false>), dim3(L.ntiles), dim3(128), 0, st, P, 0u);
+    if (L.nsmall) hipLaunchKernelGGL((zj_k0_unstuff<64, 15, true>), dim3(L.nsmall), dim3(64), 0, st, P, L.ntiles);
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1a_sync, dim3(L.nchunks / 4), dim3(256), 0, st, P);
     if (L.npacked) hipLaunchKernelGGL(zj_k1a_sync_packed, dim3(L.nchunks / 4), dim3(256), 0, st, P);

@@ -398,7 +398,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
 
     b->imgs.resize(n);
     b->unsupported.assign(n, 0);
-    std::vector<uint32_t> chunk_seg, blk256_img, k1w_img, ptile_seg, tile_seg, small_seg, dtile_seg;
+    std::vector<uint32_t> chunk_seg, blk256_img, k1w_img, ptile_seg, tile_seg, small_seg, dtile_seg, dsmall_seg;
     uint64_t nwin_total = 0;
     std::vector<uint32_t> k2_grp[ZJ_K2_CLASSES], k2_img[ZJ_K2_CLASSES]; // stage-2 workgroups per sampling layout
     std::vector<uint16_t> luts;
@@ -619,9 +619,16 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
             const uint64_t mc = ri ? std::min<uint64_t>(ri, nmcu - m0) : nmcu;
             s.first_block = d.first_block + (uint32_t)(m0 * d.bpm);
             s.nblocks = (uint32_t)(mc * d.bpm);
-            s.first_dtile = (uint32_t)dtile_seg.size();
-            s.ndtiles = (uint32_t)std::max<uint64_t>(1, (mc + 255u) / 256u);
-            for (uint32_t t = 0; t < s.ndtiles; t++) dtile_seg.push_back((uint32_t)b->segs.size());
+            if (mc <= 64u) {
+                s.first_dtile = 0;
+                s.ndtiles = 1;
+                dsmall_seg.push_back((uint32_t)b->segs.size());
+            } else {
+                s.first_dtile = (uint32_t)dtile_seg.size();
+                s.ndtiles = (uint32_t)((mc + 255u) / 256u);
+                if (s.ndtiles > 1u) b->L.ndmulti++;
+                for (uint32_t t = 0; t < s.ndtiles; t++) dtile_seg.push_back((uint32_t)b->segs.size());
+            }
             b->segs.push_back(s);
         }
         sub_in_img = (uint32_t)align_up(sub_in_img, 64);
@@ -666,6 +673,8 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     const size_t nbig = tile_seg.size(); // tiles of the 128-thread form; the short segments' entries follow them
     tile_seg.insert(tile_seg.end(), small_seg.begin(), small_seg.end());
     P.tile_seg = dev_upload(b, tile_seg);
+    const size_t nbigd = dtile_seg.size();
+    dtile_seg.insert(dtile_seg.end(), dsmall_seg.begin(), dsmall_seg.end());
     P.dtile_seg = dev_upload(b, dtile_seg);
     std::vector<uint32_t> strip_grp_all, strip_img_all;
     for (int c = 0; c < ZJ_K2_CLASSES; c++) {
@@ -713,7 +722,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     }
     if (ok) {
         const int S = ZJ_MEM_SCRATCH;
-        P.dtile_sum = dev_alloc<uint32_t>(b, dtile_seg.size() * 4, true, S);
+        P.dtile_sum = dev_alloc<uint32_t>(b, (nbigd + 1) * 4, true, S);
         P.tile_status = dev_alloc<uint64_t>(b, nbig + (b->segs.size() + 1) / 2 + 1, true, S);
         P.seg_ticket = P.tile_status ? reinterpret_cast<uint32_t *>(P.tile_status + nbig) : nullptr;
         P.ust = dev_alloc<uint8_t>(b, ust_total + 1040, true, S);
@@ -764,7 +773,8 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     b->L.nptiles = (uint32_t)ptile_seg.size();
     b->L.ntiles = (uint32_t)nbig;
     b->L.nsmall = (uint32_t)small_seg.size();
-    b->L.ndtiles = (uint32_t)dtile_seg.size();
+    b->L.ndtiles = (uint32_t)nbigd;
+    b->L.ndsmall = (uint32_t)dsmall_seg.size();
     b->L.nstrips = (uint32_t)strip_grp_all.size();
     b->L.fix_iters = 1;
     ctx->err_code = ZJ_OK;

@@ -30,7 +30,7 @@ struct ZjParams {
     uint32_t *wbase;            // per segment: [window in stream order] blocks that begin earlier in the segment
     uint8_t *bitmap;            // block-start bitmap, laid out like `ust` (one bit per stream bit)
     const uint32_t *ptile_seg;  // [position-pass workgroup] segment
-    const uint32_t *dtile_seg;  // [DC-scan tile of 256 MCUs] segment
+    const uint32_t *dtile_seg;  // [DC-scan tile of 256 MCUs] segment; behind the tiles, the segments of at most 64 MCUs
     uint32_t *dtile_sum;        // [DC-scan tile][4] per component: sum of the tile's differences, then of the tiles before it
     const uint32_t *tile_seg;   // [unstuff tile] segment; behind the tiles, the segments short enough for one small tile each
     uint64_t *tile_status;      // [unstuff tile] look-back word: flag << 32 | bytes
@@ -68,6 +68,8 @@ __host__ __device__ constexpr uint32_t zj_k2_wave_mcus(uint32_t hs, uint32_t vs)
 struct ZjLaunch {
     uint32_t nseg, nchunks, nblk256, nstrips, nk1w, nptiles, ntiles, ndtiles;
     uint32_t nsmall;  // segments unstuffed by the one-wavefront form; their entries of tile_seg follow the `ntiles` others
+    uint32_t ndsmall; // segments of at most 64 MCUs, scanned by one wavefront each; their entries of dtile_seg follow the `ndtiles` others
+    uint32_t ndmulti; // segments of more than one DC-scan tile
     uint32_t npacked; // chunks shared by several short segments (the packed form of the sync kernel)
     uint32_t k2_first[ZJ_K2_CLASSES], k2_count[ZJ_K2_CLASSES]; // stage-2 workgroups per layout (2x2, 1x1, 2x1, 1x2, one component)
     int fix_iters;

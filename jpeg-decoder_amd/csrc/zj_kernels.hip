@@ -911,6 +911,34 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan(ZjParams P)
     }
 }
 
+// The same for segments of at most 64 MCUs (short restart intervals), which the planner lists apart: one
+// wavefront per segment, four segments per workgroup, no shared memory and no barrier.
+__global__ __launch_bounds__(256) void zj_k1d_dcscan_small(ZjParams P, uint32_t first, uint32_t count)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+    if (idx >= count) return;
+    const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.dtile_seg[first + idx]);
+    const ZjSegDev sg = P.segs[s];
+    const ZjImgDev im = P.imgs[sg.img]; // by value: a reference would be read again after every store
+    const uint32_t bpm = im.bpm, compsel = im.compsel;
+    const uint32_t nmcu = sg.nblocks / bpm;
+    int16_t *da = P.dcabs + sg.first_block; // holds the differences on entry
+    const ZjDcTile t = zj_dc_tile_load(da, lane, nmcu, bpm, compsel);
+    uint32_t run[3];
+#pragma unroll
+    for (uint32_t cc = 0; cc < 3u; cc++) run[cc] = wave_incl_scan(t.loc[cc], lane) - t.loc[cc];
+#pragma unroll
+    for (uint32_t k = 0; k < 6u; k++) {
+        const uint32_t c = (compsel >> (2u * k)) & 3u;
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t cc = 0; cc < 3u; cc++)
+            if (c == cc && k < bpm) { run[cc] += t.d[k]; v = run[cc]; }
+        if (k < bpm && lane < nmcu) da[lane * bpm + k] = (int16_t)v;
+    }
+}
+
 // ---------------------------------------------------------------------------------- k1w: write
 // One lane per block.  A wavefront owns a run of MCUs and works through it in rounds of 64 blocks of
 // one kind -- all luma blocks first, then all chroma blocks -- because luma blocks carry several
@@ -1677,6 +1705,16 @@ __global__ __launch_bounds__(256) void zj_kx_dequant(ZjParams P, uint32_t ii, in
 }
 
 // ---------------------------------------------------------------------------------- launchers
+static void zj_launch_dcscan(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
+{
+    if (L.ndmulti) { // segments of more than one tile: their tile sums first
+        hipLaunchKernelGGL(zj_k1d_tilesum, dim3(L.ndtiles), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(zj_k1d_tilescan, dim3(L.nseg), dim3(256), 0, st, P);
+    }
+    if (L.ndtiles) hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.ndtiles), dim3(256), 0, st, P);
+    if (L.ndsmall) hipLaunchKernelGGL(zj_k1d_dcscan_small, dim3((L.ndsmall + 3u) / 4u), dim3(256), 0, st, P, L.ndtiles, L.ndsmall);
+}
+
 extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream_t st, hipEvent_t *ev)
 {
     int e = 0;
@@ -1696,11 +1734,7 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1c_dcdiff, dim3((L.nblk256 + ZJ_K1C_NB - 1) / ZJ_K1C_NB), dim3(256), 0, st, P, L.nblk256);
-    if (L.ndtiles) {
-        hipLaunchKernelGGL(zj_k1d_tilesum, dim3(L.ndtiles), dim3(256), 0, st, P);
-        hipLaunchKernelGGL(zj_k1d_tilescan, dim3(L.nseg), dim3(256), 0, st, P);
-        hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.ndtiles), dim3(256), 0, st, P);
-    }
+    zj_launch_dcscan(P, L, st);
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
@@ -1724,11 +1758,7 @@ extern "C" void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipS
     hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
     if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1c_dcdiff, dim3((L.nblk256 + ZJ_K1C_NB - 1) / ZJ_K1C_NB), dim3(256), 0, st, P, L.nblk256);
-    if (L.ndtiles) {
-        hipLaunchKernelGGL(zj_k1d_tilesum, dim3(L.ndtiles), dim3(256), 0, st, P);
-        hipLaunchKernelGGL(zj_k1d_tilescan, dim3(L.nseg), dim3(256), 0, st, P);
-        hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.ndtiles), dim3(256), 0, st, P);
-    }
+    zj_launch_dcscan(P, L, st);
     hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
 }
 

@@ -191,6 +191,19 @@ int zj_batch_memory(zj_batch *b, size_t *plan_bytes, size_t *scratch_bytes);
  * stream; allocates nothing. */
 int zj_batch_decode(zj_batch *b, uint8_t *const *rgb, const size_t *stride);
 
+/* The two halves of zj_batch_decode on their own: the entropy passes (src/decoder.rs:337-404, up to the
+ * coefficients) on the context's stream, and IDCT + colour conversion (src/decoder.rs:408-561) on `stream`
+ * -- NULL for the context's, or another stream of the caller's on the same device, which is made to wait
+ * for the entropy passes.  The entropy passes keep the arithmetic units busy and the pixel pass the memory
+ * system, so a caller with several batches gains by giving the pixel passes a stream of their own: the
+ * pixel pass of one batch then runs beside the entropy passes of the next.  With a stream of its own the
+ * pixels are ready when THAT stream reaches the point behind the call; zj_batch_finish and zj_batch_destroy
+ * wait for it as well, and the batch's next entropy pass is ordered behind it.  A batch whose scratch
+ * belongs to a workspace holds the context's stream back until its pixels are out (no overlap there:
+ * the next batch's entropy passes would overwrite the coefficients). */
+int zj_batch_decode_entropy(zj_batch *b);
+int zj_batch_decode_pixels(zj_batch *b, uint8_t *const *rgb, const size_t *stride, void *stream);
+
 /* Wait for the stream, then copy out the per-image status words (n entries).  If the device
  * reported that subsequence synchronisation had not converged, this call reruns the decode with
  * the exhaustive fix-up loop before returning (never observed on real streams). */

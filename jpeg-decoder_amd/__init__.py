@@ -6,5 +6,5 @@ decoder    Decoder / ParsedImage / Batch: the host-side mirror of the reference'
 shard      batch partitioning over GPUs and band splitting of restart-marked images
 synth      synthetic JPEG generator for benchmarks and tests
 """
-from .decoder import (Batch, Context, DecodeError, Decoder, ParsedImage, Workspace, decode_images,  # noqa: F401
-                      decode_noalloc)
+from .decoder import (Batch, Context, DecodeError, Decoder, OutputTables, ParsedImage, Workspace,  # noqa: F401
+                      decode_images, decode_noalloc)

@@ -61,6 +61,7 @@ _EXPORTS = [
     "zj_workspace_estimate", "zj_workspace_create", "zj_workspace_destroy", "zj_batch_create_in", "zj_batch_memory",
     "zj_batch_counters", "zj_batch_create_rows",
     "zj_decode_batch_noalloc",
+    "zj_batch_decode_entropy", "zj_batch_decode_pixels",
 ]
 
 
@@ -110,6 +111,8 @@ def lib():
     L.zj_batch_create_rows.argtypes = [vp, C.POINTER(zj_image), sz, C.c_uint32, u32p, u32p]; L.zj_batch_create_rows.restype = vp
     L.zj_batch_counters.argtypes = [vp, u32p]; L.zj_batch_counters.restype = C.c_int
     L.zj_decode_batch_noalloc.argtypes = [vp, C.POINTER(zj_image), sz, C.POINTER(vp), C.POINTER(sz), u32p]; L.zj_decode_batch_noalloc.restype = C.c_int
+    L.zj_batch_decode_entropy.argtypes = [vp]; L.zj_batch_decode_entropy.restype = C.c_int
+    L.zj_batch_decode_pixels.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), vp]; L.zj_batch_decode_pixels.restype = C.c_int
     _lib = L
     return L
 

@@ -81,6 +81,11 @@ struct zj_batch {
     uint32_t *h_flags;        // 4 words
     hipEvent_t tables_copied; // recorded behind the copies that read h_rgb / h_stride
     bool tables_ev_valid, tables_ev_pending;
+    // zj_batch_decode_entropy / zj_batch_decode_pixels: the two halves of a decode call, the second possibly on
+    // another stream; created on first use of such a stream
+    hipEvent_t entropy_done, pixels_done;
+    bool entropy_launched;
+    bool split_ev_valid, pixels_pending; // pixels_pending: pixels_done was recorded on a stream other than the context's
     uint32_t slow_path_calls; // zj_batch_finish calls that had to run the exhaustive fix-up loop
     uint64_t scan_bytes, coef_bytes, rgb_bytes, pixels;
     bool profiling;
@@ -287,6 +292,7 @@ extern "C" void zj_batch_destroy(zj_batch *b)
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->pixels_pending) (void)hipEventSynchronize(b->pixels_done);
     if (b->ws) (void)hipStreamSynchronize(b->ws->copy_stream);
     for (void *p : b->allocs) (void)hipFree(p);
     if (b->pinned) {
@@ -299,6 +305,7 @@ extern "C" void zj_batch_destroy(zj_batch *b)
     if (b->ev_valid)
         for (auto &e : b->ev) (void)hipEventDestroy(e);
     if (b->ready_valid) (void)hipEventDestroy(b->ready);
+    if (b->split_ev_valid) { (void)hipEventDestroy(b->entropy_done); (void)hipEventDestroy(b->pixels_done); }
     if (b->tables_ev_valid) (void)hipEventDestroy(b->tables_copied);
     delete b;
 }
@@ -356,6 +363,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     b->ev_valid = false; b->profiling = false; b->decoded = false;
     b->ready_valid = false; b->ready_waited = false; b->tables_ev_valid = false; b->tables_ev_pending = false;
     b->slow_path_calls = 0;
+    b->entropy_launched = false; b->split_ev_valid = false; b->pixels_pending = false;
     b->scan_bytes = b->coef_bytes = b->rgb_bytes = b->pixels = 0;
     b->ws = nullptr;
     b->up = ctx->stream;
@@ -871,12 +879,46 @@ extern "C" int zj_batch_memory(zj_batch *b, size_t *plan_bytes, size_t *scratch_
     return ZJ_OK;
 }
 
-extern "C" int zj_batch_decode(zj_batch *b, uint8_t *const *rgb, const size_t *stride)
+// The entropy passes (everything up to the coefficients) on the context's stream.
+static int decode_entropy(zj_batch *b)
 {
-    if (!b) return ZJ_E_INVALID;
     zj_ctx *c = b->ctx;
     if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return ZJ_E_DEVICE;
     hipStream_t st = c->stream;
+    if (b->pixels_pending) {
+        // the IDCT of the previous call may still be reading the coefficients on its own stream
+        if (!hip_ok(c, hipStreamWaitEvent(st, b->pixels_done, 0), "stream wait")) return ZJ_E_DEVICE;
+        b->pixels_pending = false;
+    }
+    if (b->ready_valid && !b->ready_waited) {
+        if (!hip_ok(c, hipStreamWaitEvent(st, b->ready, 0), "stream wait")) return ZJ_E_DEVICE;
+        b->ready_waited = true;
+    }
+    if (b->n && !hip_ok(c, hipMemsetAsync(b->P.status, 0, b->n * sizeof(uint32_t), st), "memset status")) return ZJ_E_DEVICE;
+    b->entropy_launched = true;
+    if (b->L.nchunks == 0) return ZJ_OK;
+    hipEvent_t *ev = nullptr;
+    if (b->profiling) {
+        if (!b->ev_valid) {
+            for (auto &e : b->ev)
+                if (!hip_ok(c, hipEventCreate(&e), "hipEventCreate")) return ZJ_E_DEVICE;
+            b->ev_valid = true;
+        }
+        ev = b->ev;
+    }
+    zj_launch_stage1(b->P, b->L, st, ev);
+    if (!hip_ok(c, hipGetLastError(), "kernel launch")) return ZJ_E_DEVICE;
+    return ZJ_OK;
+}
+
+// IDCT and colour conversion into the caller's buffers, on `ps` (the context's stream, or one of the caller's
+// that is made to wait for the entropy passes).
+static int decode_pixels(zj_batch *b, uint8_t *const *rgb, const size_t *stride, hipStream_t ps)
+{
+    zj_ctx *c = b->ctx;
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return ZJ_E_DEVICE;
+    hipStream_t st = c->stream;
+    if (!b->entropy_launched) { c->err = "zj_batch_decode_pixels before zj_batch_decode_entropy"; return ZJ_E_INVALID; }
     for (size_t i = 0; i < b->n; i++) {
         if (rgb && rgb[i] && !b->unsupported[i] && stride && stride[i] && stride[i] < (size_t)b->imgs[i].w * 3u) {
             c->err = "output pitch is smaller than 3 * width";
@@ -894,36 +936,62 @@ extern "C" int zj_batch_decode(zj_batch *b, uint8_t *const *rgb, const size_t *s
         b->h_stride[i] = stride ? stride[i] : 0;
         any_rgb = any_rgb || b->h_rgb[i];
     }
-    if (b->ready_valid && !b->ready_waited) {
-        if (!hip_ok(c, hipStreamWaitEvent(st, b->ready, 0), "stream wait")) return ZJ_E_DEVICE;
-        b->ready_waited = true;
+    if (ps != st) {
+        if (!b->split_ev_valid) {
+            if (!hip_ok(c, hipEventCreateWithFlags(&b->entropy_done, hipEventDisableTiming), "hipEventCreate")) return ZJ_E_DEVICE;
+            if (!hip_ok(c, hipEventCreateWithFlags(&b->pixels_done, hipEventDisableTiming), "hipEventCreate")) { (void)hipEventDestroy(b->entropy_done); return ZJ_E_DEVICE; }
+            b->split_ev_valid = true;
+        }
+        if (!hip_ok(c, hipEventRecord(b->entropy_done, st), "event record")) return ZJ_E_DEVICE;
+        if (!hip_ok(c, hipStreamWaitEvent(ps, b->entropy_done, 0), "stream wait")) return ZJ_E_DEVICE;
     }
     if (b->n) {
-        if (!hip_ok(c, hipMemcpyAsync(b->d_rgb, b->h_rgb, b->n * sizeof(uint8_t *), hipMemcpyHostToDevice, st), "H2D rgb table")) return ZJ_E_DEVICE;
-        if (!hip_ok(c, hipMemcpyAsync(b->d_stride, b->h_stride, b->n * sizeof(size_t), hipMemcpyHostToDevice, st), "H2D stride table")) return ZJ_E_DEVICE;
+        if (!hip_ok(c, hipMemcpyAsync(b->d_rgb, b->h_rgb, b->n * sizeof(uint8_t *), hipMemcpyHostToDevice, ps), "H2D rgb table")) return ZJ_E_DEVICE;
+        if (!hip_ok(c, hipMemcpyAsync(b->d_stride, b->h_stride, b->n * sizeof(size_t), hipMemcpyHostToDevice, ps), "H2D stride table")) return ZJ_E_DEVICE;
         if (b->tables_ev_valid) {
-            if (!hip_ok(c, hipEventRecord(b->tables_copied, st), "event record")) return ZJ_E_DEVICE;
+            if (!hip_ok(c, hipEventRecord(b->tables_copied, ps), "event record")) return ZJ_E_DEVICE;
             b->tables_ev_pending = true;
         }
-        if (!hip_ok(c, hipMemsetAsync(b->P.status, 0, b->n * sizeof(uint32_t), st), "memset status")) return ZJ_E_DEVICE;
     }
-    if (b->L.nchunks == 0) { b->decoded = true; return ZJ_OK; }
-    hipEvent_t *ev = nullptr;
-    if (b->profiling) {
-        if (!b->ev_valid) {
-            for (auto &e : b->ev)
-                if (!hip_ok(c, hipEventCreate(&e), "hipEventCreate")) return ZJ_E_DEVICE;
-            b->ev_valid = true;
-        }
-        ev = b->ev;
+    if (b->L.nchunks) {
+        ZjLaunch L2 = b->L;
+        if (!any_rgb) { L2.nstrips = 0; for (int k = 0; k < ZJ_K2_CLASSES; k++) L2.k2_count[k] = 0; }
+        zj_launch_stage2(b->P, L2, ps, (b->profiling && b->ev_valid) ? b->ev + 8 : nullptr);
+        if (!hip_ok(c, hipGetLastError(), "kernel launch")) return ZJ_E_DEVICE;
     }
-    zj_launch_stage1(b->P, b->L, st, ev);
-    ZjLaunch L2 = b->L;
-    if (!any_rgb) { L2.nstrips = 0; for (int c = 0; c < ZJ_K2_CLASSES; c++) L2.k2_count[c] = 0; }
-    zj_launch_stage2(b->P, L2, st, ev ? ev + 8 : nullptr);
-    if (!hip_ok(c, hipGetLastError(), "kernel launch")) return ZJ_E_DEVICE;
+    if (ps != st) {
+        if (!hip_ok(c, hipEventRecord(b->pixels_done, ps), "event record")) return ZJ_E_DEVICE;
+        b->pixels_pending = true;
+        // scratch shared with other batches: their entropy passes must not start before these pixels are out
+        if (b->scratch_pooled && !hip_ok(c, hipStreamWaitEvent(st, b->pixels_done, 0), "stream wait")) return ZJ_E_DEVICE;
+    }
     b->decoded = true;
     return ZJ_OK;
+}
+
+extern "C" int zj_batch_decode(zj_batch *b, uint8_t *const *rgb, const size_t *stride)
+{
+    if (!b) return ZJ_E_INVALID;
+    // the checks of the second half first: a call that is going to be refused launches nothing
+    for (size_t i = 0; i < b->n; i++) {
+        if (rgb && rgb[i] && !b->unsupported[i] && stride && stride[i] && stride[i] < (size_t)b->imgs[i].w * 3u) {
+            b->ctx->err = "output pitch is smaller than 3 * width";
+            return ZJ_E_INVALID;
+        }
+    }
+    const int rc = decode_entropy(b);
+    return rc != ZJ_OK ? rc : decode_pixels(b, rgb, stride, b->ctx->stream);
+}
+
+extern "C" int zj_batch_decode_entropy(zj_batch *b)
+{
+    return b ? decode_entropy(b) : ZJ_E_INVALID;
+}
+
+extern "C" int zj_batch_decode_pixels(zj_batch *b, uint8_t *const *rgb, const size_t *stride, void *stream)
+{
+    if (!b) return ZJ_E_INVALID;
+    return decode_pixels(b, rgb, stride, stream ? (hipStream_t)stream : b->ctx->stream);
 }
 
 extern "C" int zj_batch_finish(zj_batch *b, uint32_t *status)
@@ -933,6 +1001,10 @@ extern "C" int zj_batch_finish(zj_batch *b, uint32_t *status)
     if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return ZJ_E_DEVICE;
     hipStream_t st = c->stream;
     if (!hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
+    if (b->pixels_pending) {
+        if (!hip_ok(c, hipEventSynchronize(b->pixels_done), "event sync")) return ZJ_E_DEVICE;
+        b->pixels_pending = false;
+    }
     if (b->decoded && b->L.nchunks) {
         if (!hip_ok(c, hipMemcpy(b->h_flags, b->P.flags, 16, hipMemcpyDeviceToHost), "D2H flags")) return ZJ_E_DEVICE;
         if (b->h_flags[0] || b->h_flags[1]) {

@@ -170,6 +170,21 @@ class Workspace:
             pass
 
 
+class OutputTables:
+    """Addresses and row pitches of a batch's output tensors, checked against the batch's images."""
+
+    def __init__(self, batch, rgb_tensors):
+        n = batch.n
+        self.batch, self.tensors = batch, list(rgb_tensors)
+        self.ptrs = (C.c_void_p * max(n, 1))()
+        self.strides = (C.c_size_t * max(n, 1))()
+        for i, t in enumerate(self.tensors):
+            if t is not None:
+                check_output_tensor(t, batch.images[i], batch.ctx.device, batch.window_height(i))
+                self.ptrs[i] = t.data_ptr()
+                self.strides[i] = t.stride(0)
+
+
 class Batch:
     """A planned batch of parsed images, resident on the GPU (zj_batch_create, or zj_batch_create_in
     when a workspace and one of its plan slots are given)."""
@@ -214,19 +229,38 @@ class Batch:
         mh = 8 * max(im.image.vsamp[0], 1)
         return min(self.rows[i][1] * mh, im.height - self.rows[i][0] * mh)
 
+    def output_tables(self, rgb_tensors):
+        """Check the output tensors once and keep their addresses and pitches: the result can be passed to
+        decode() / decode_pixels() in place of the list, which saves the per-tensor checks on every call."""
+        return OutputTables(self, rgb_tensors)
+
+    def _output_tables(self, rgb_tensors):
+        if rgb_tensors is None:
+            self._rgb = None
+            return None, (C.c_size_t * max(self.n, 1))()
+        t = rgb_tensors if isinstance(rgb_tensors, OutputTables) else OutputTables(self, rgb_tensors)
+        if t.batch is not self:
+            raise ValueError("output tables of another batch")
+        self._rgb = t.tensors  # keeps them alive while the GPU writes
+        return t.ptrs, t.strides
+
     def decode(self, rgb_tensors=None):
         """Launch the hot path (asynchronous).  rgb_tensors: list of 2-D uint8 CUDA tensors or None."""
-        n = self.n
-        ptrs = (C.c_void_p * max(n, 1))()
-        strides = (C.c_size_t * max(n, 1))()
-        if rgb_tensors is not None:
-            for i, t in enumerate(rgb_tensors):
-                if t is not None:
-                    check_output_tensor(t, self.images[i], self.ctx.device, self.window_height(i))
-                    ptrs[i] = t.data_ptr()
-                    strides[i] = t.stride(0)
-        self._rgb = rgb_tensors
-        rc = B.lib().zj_batch_decode(self.h, ptrs if rgb_tensors is not None else None, strides)
+        ptrs, strides = self._output_tables(rgb_tensors)
+        rc = B.lib().zj_batch_decode(self.h, ptrs, strides)
+        if rc != B.ZJ_OK:
+            raise DecodeError("device", self.ctx.last_error())
+
+    def decode_entropy(self):
+        """First half of decode(): the entropy passes, on the context's stream (zj_batch_decode_entropy)."""
+        if B.lib().zj_batch_decode_entropy(self.h) != B.ZJ_OK:
+            raise DecodeError("device", self.ctx.last_error())
+
+    def decode_pixels(self, rgb_tensors=None, stream=None):
+        """Second half of decode(): IDCT and colour conversion, on `stream` (a raw HIP stream handle; None: the
+        context's stream), which is made to wait for the entropy passes (zj_batch_decode_pixels)."""
+        ptrs, strides = self._output_tables(rgb_tensors)
+        rc = B.lib().zj_batch_decode_pixels(self.h, ptrs, strides, stream)
         if rc != B.ZJ_OK:
             raise DecodeError("device", self.ctx.last_error())
 
@@ -290,6 +324,7 @@ class Batch:
         if self.h:
             B.lib().zj_batch_destroy(self.h)
             self.h = None
+        self._rgb = None
 
     def __del__(self):
         try:

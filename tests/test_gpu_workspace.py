@@ -164,3 +164,43 @@ def test_decode_rejects_bad_output_geometry(ctx):
     b.decode([ok])
     assert b.finish()[0] == 0
     b.close()
+
+
+def test_pixel_pass_on_a_stream_of_its_own(ctx):
+    """zj_batch_decode_entropy + zj_batch_decode_pixels on a second stream give what zj_batch_decode gives, for
+    two batches whose halves interleave (entropy 0, pixels 0, entropy 1, pixels 1), repeated so that an entropy
+    pass follows the same batch's pixel pass on the other stream; also with the scratch in a workspace, and
+    with output tables prepared once."""
+    import torch
+    fa = [synth.encode(1920, 1080, 2, 2, 90, 0, 301, 0), synth.encode(640, 480, 1, 1, 90, 2, 302, 7)]
+    fb = [synth.encode(1280, 720, 2, 1, 85, 0, 303, 0), synth.encode(333, 211, 2, 2, 90, 1, 304, 3), synth.encode(64, 64, 0, 0, 90, 0, 305, 0)]
+    ia, ib = [J.ParsedImage(f) for f in fa], [J.ParsedImage(f) for f in fb]
+    pix = torch.cuda.Stream()
+    ests = [J.Workspace.estimate(ia), J.Workspace.estimate(ib)]
+    ws = J.Workspace(ctx, max(e[1] for e in ests), max(e[0] for e in ests), 2)
+    for shared in (False, True):
+        ba = J.Batch(ctx, ia, workspace=ws, slot=0) if shared else J.Batch(ctx, ia)
+        bb = J.Batch(ctx, ib, workspace=ws, slot=1) if shared else J.Batch(ctx, ib)
+        oa, ob = ba.alloc_rgb(), bb.alloc_rgb()
+        ta, tb = ba.output_tables(oa), bb.output_tables(ob)
+        with pytest.raises(J.DecodeError):
+            ba.decode_pixels(ta, pix.cuda_stream)  # nothing to convert yet
+        for rep in range(3):
+            for o in oa + ob:
+                o.fill_(0x5A)
+            torch.cuda.synchronize()
+            ba.decode_entropy()
+            ba.decode_pixels(ta, pix.cuda_stream)
+            bb.decode_entropy()
+            bb.decode_pixels(tb if rep else ob, pix.cuda_stream)
+            _check(fb, ib, ob, bb.finish())  # finish waits for the pixel stream as well
+            _check(fa, ia, oa, ba.finish())
+        # and the two halves on the context's own stream
+        for o in oa:
+            o.fill_(0)
+        ba.decode_entropy()
+        ba.decode_pixels(ta)
+        _check(fa, ia, oa, ba.finish(), None if shared else ba)
+        ba.close(); bb.close()
+    with pytest.raises(ValueError):
+        J.Batch(ctx, ia).decode(tb)  # tables of another batch

@@ -174,6 +174,8 @@ def test_null_handles_are_errors_not_crashes():
     v = [C.c_uint64() for _ in range(4)]
     assert not L.zj_batch_create(None, None, 0, 0)
     assert L.zj_batch_decode(None, None, None) == B.ZJ_E_INVALID
+    assert L.zj_batch_decode_entropy(None) == B.ZJ_E_INVALID
+    assert L.zj_batch_decode_pixels(None, None, None, None) == B.ZJ_E_INVALID
     assert L.zj_batch_finish(None, st) == B.ZJ_E_INVALID
     assert not L.zj_batch_qcoef(None, 0)
     assert L.zj_batch_export_coef(None, 0, None, None, B.ZJ_MEM_HOST) == B.ZJ_E_INVALID

@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sampling", default="420", choices=["420", "444", "422", "440"])
+    ap.add_argument("--no-overlap", action="store_true", help="c4: one workspace and one stream (no overlap of a sub-batch's pixel pass with the next one's entropy passes)")
     ap.add_argument("--quality", type=int, default=90)
     ap.add_argument("--content", type=int, default=0, help="0 natural, 1 smooth, 2 white noise")
     ap.add_argument("--subseq-bits", type=int, default=0)
@@ -456,11 +457,17 @@ def run_c4(a, D):
     sub = max(1, a.sub_batch)
     groups = [my_keys[g: g + sub] for g in range(0, len(my_keys), sub)]
     est = [J.Workspace.estimate([parsed[k] for k in g]) for g in groups]
-    ws = J.Workspace(ctx, max(e[1] for e in est), max(e[0] for e in est), len(groups))
+    # Sub-batches alternate between two workspaces (two scratch ranges), and the IDCT/colour pass runs on a stream
+    # of its own: the pixel pass of one sub-batch overlaps the entropy passes of the next, which hides the tails
+    # of the kernels of either.  One workspace and one stream with --no-overlap or a single sub-batch.
+    overlap = len(groups) > 1 and not a.no_overlap
+    pix = torch.cuda.Stream(device=dev) if overlap else None
+    nws = 2 if overlap else 1
+    wss = [J.Workspace(ctx, max(e[1] for e in est), max(e[0] for e in est), (len(groups) + nws - 1) // nws) for _ in range(nws)]
     batches, outs, tables = [], {}, {}
     S = Cb = P = px = 0
-    for slot, g in enumerate(groups):
-        b = J.Batch(ctx, [parsed[k] for k in g], a.subseq_bits, workspace=ws, slot=slot)
+    for gi, g in enumerate(groups):
+        b = J.Batch(ctx, [parsed[k] for k in g], a.subseq_bits, workspace=wss[gi % nws], slot=gi // nws)
         batches.append(b)
         outs[id(b)] = b.alloc_rgb()
         tables[id(b)] = b.output_tables(outs[id(b)])
@@ -468,8 +475,14 @@ def run_c4(a, D):
         S, Cb, P, px = S + bc["scan"], Cb + bc["coef"], P + bc["rgb"], px + bc["pixels"]
 
     def step():
+        if not overlap:
+            for b in batches:
+                b.decode(tables[id(b)])
+            return
         for b in batches:
-            b.decode(tables[id(b)])
+            b.decode_entropy()
+            b.decode_pixels(tables[id(b)], pix.cuda_stream)
+        stream.wait_stream(pix)  # the step is over when its last pixels are out
 
     def check():
         for b in batches:
@@ -505,7 +518,7 @@ def run_c4(a, D):
             "vs_baseline": None, "dtype": "u8/i16 entropy decode, f32 IDCT+colour", "data": "synthetic",
             "config": {"workload": f"c4: mixed job of {total} images ({per_gpu} per GPU), 1920x1080 / 3840x2160 x 4:2:0 / 4:4:4 in equal "
                                    f"parts, q{a.quality}, {4 * nseed} distinct files cycled",
-                       "images_per_gpu": len(my_keys), "sub_batches": len(groups), "sub_batch_images": sub, "timing": "device-resident",
+                       "images_per_gpu": len(my_keys), "sub_batches": len(groups), "sub_batch_images": sub, "pixel_pass_on_its_own_stream": overlap, "timing": "device-resident",
                        "sharding": "by image, longest-processing-time-first on scan bytes, no collective",
                        "workspace_bytes": {"scratch_shared": max(e[1] for e in est), "plan_per_sub_batch": max(e[0] for e in est)}},
             "roofline": roofline_fields(kt, S, Cb, P),
@@ -522,7 +535,8 @@ def run_c4(a, D):
     assert ok, "GPU output differs from the oracle"
     for b in batches:
         b.close()
-    ws.close()
+    for ws in wss:
+        ws.close()
     ctx.close()
     return result
 

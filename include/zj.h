@@ -198,9 +198,9 @@ int zj_batch_decode(zj_batch *b, uint8_t *const *rgb, const size_t *stride);
  * system, so a caller with several batches gains by giving the pixel passes a stream of their own: the
  * pixel pass of one batch then runs beside the entropy passes of the next.  With a stream of its own the
  * pixels are ready when THAT stream reaches the point behind the call; zj_batch_finish and zj_batch_destroy
- * wait for it as well, and the batch's next entropy pass is ordered behind it.  A batch whose scratch
- * belongs to a workspace holds the context's stream back until its pixels are out (no overlap there:
- * the next batch's entropy passes would overwrite the coefficients). */
+ * wait for it as well, and the batch's next entropy pass is ordered behind it.  When the scratch belongs
+ * to a workspace, the next entropy pass of ANY batch of that workspace is ordered behind these pixels (it
+ * would overwrite the coefficients they are made from): to overlap, alternate between two workspaces. */
 int zj_batch_decode_entropy(zj_batch *b);
 int zj_batch_decode_pixels(zj_batch *b, uint8_t *const *rgb, const size_t *stride, void *stream);
 

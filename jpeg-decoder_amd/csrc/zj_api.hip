@@ -51,6 +51,10 @@ struct zj_workspace {
     hipEvent_t stage_free[2]; // recorded behind the copy that reads stage[k]
     bool stage_used[2];
     size_t stage_bytes;
+    // recorded behind the last pixel pass that a batch of this workspace ran on a stream other than the
+    // context's: the next entropy pass on the shared scratch waits for it
+    hipEvent_t pix_ev;
+    bool pix_ev_valid, pix_pending;
 };
 
 struct zj_batch {
@@ -831,6 +835,10 @@ extern "C" void zj_workspace_destroy(zj_workspace *ws)
     (void)hipSetDevice(ws->ctx->device);
     if (ws->copy_stream) { (void)hipStreamSynchronize(ws->copy_stream); (void)hipStreamDestroy(ws->copy_stream); }
     (void)hipStreamSynchronize(ws->ctx->stream);
+    if (ws->pix_ev_valid) {
+        if (ws->pix_pending) (void)hipEventSynchronize(ws->pix_ev);
+        (void)hipEventDestroy(ws->pix_ev);
+    }
     for (int k = 0; k < 2; k++) {
         if (ws->stage[k]) (void)hipHostFree(ws->stage[k]);
         if (ws->stage_free[k]) (void)hipEventDestroy(ws->stage_free[k]);
@@ -889,6 +897,11 @@ static int decode_entropy(zj_batch *b)
         // the IDCT of the previous call may still be reading the coefficients on its own stream
         if (!hip_ok(c, hipStreamWaitEvent(st, b->pixels_done, 0), "stream wait")) return ZJ_E_DEVICE;
         b->pixels_pending = false;
+    }
+    if (b->scratch_pooled && b->ws && b->ws->pix_pending) {
+        // so may the IDCT of another batch on the same scratch
+        if (!hip_ok(c, hipStreamWaitEvent(st, b->ws->pix_ev, 0), "stream wait")) return ZJ_E_DEVICE;
+        b->ws->pix_pending = false;
     }
     if (b->ready_valid && !b->ready_waited) {
         if (!hip_ok(c, hipStreamWaitEvent(st, b->ready, 0), "stream wait")) return ZJ_E_DEVICE;
@@ -963,7 +976,15 @@ static int decode_pixels(zj_batch *b, uint8_t *const *rgb, const size_t *stride,
         if (!hip_ok(c, hipEventRecord(b->pixels_done, ps), "event record")) return ZJ_E_DEVICE;
         b->pixels_pending = true;
         // scratch shared with other batches: their entropy passes must not start before these pixels are out
-        if (b->scratch_pooled && !hip_ok(c, hipStreamWaitEvent(st, b->pixels_done, 0), "stream wait")) return ZJ_E_DEVICE;
+        if (b->scratch_pooled && b->ws) {
+            zj_workspace *ws = b->ws;
+            if (!ws->pix_ev_valid) {
+                if (!hip_ok(c, hipEventCreateWithFlags(&ws->pix_ev, hipEventDisableTiming), "hipEventCreate")) return ZJ_E_DEVICE;
+                ws->pix_ev_valid = true;
+            }
+            if (!hip_ok(c, hipEventRecord(ws->pix_ev, ps), "event record")) return ZJ_E_DEVICE;
+            ws->pix_pending = true;
+        } else if (b->scratch_pooled && !hip_ok(c, hipStreamWaitEvent(st, b->pixels_done, 0), "stream wait")) return ZJ_E_DEVICE;
     }
     b->decoded = true;
     return ZJ_OK;

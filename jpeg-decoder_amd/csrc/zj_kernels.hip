@@ -705,17 +705,45 @@ __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
     const uint32_t *rec = P.winfo + sg.first_win;
     uint32_t *wb = P.wbase + sg.first_win;
     uint32_t carry = 0;
-    for (uint32_t t0 = 0; t0 < nwin; t0 += 256u) {
-        const uint32_t wi = t0 + threadIdx.x;
-        uint32_t n = 0;
-        if (wi < nwin) {
-            const uint32_t q = wi / NC, c = wi - q * NC;
-            n = rec[zj_rec_index(q, c, NC, sg.lanes)] >> 16;
+    if (P.nseg >= 256u) {
+        // enough segments to fill the GPU: one window per thread and step, neighbouring threads read neighbouring records
+        for (uint32_t t0 = 0; t0 < nwin; t0 += 256u) {
+            const uint32_t wi = t0 + threadIdx.x;
+            uint32_t n = 0;
+            if (wi < nwin) {
+                const uint32_t q = wi / NC, c = wi - q * NC;
+                n = rec[zj_rec_index(q, c, NC, sg.lanes)] >> 16;
+            }
+            uint32_t total;
+            uint32_t inc = block_incl_scan<4>(n, wsum, &total);
+            if (wi < nwin) wb[wi] = carry + inc - n;
+            carry += total;
         }
-        uint32_t total;
-        uint32_t inc = block_incl_scan<4>(n, wsum, &total);
-        if (wi < nwin) wb[wi] = carry + inc - n;
-        carry += total;
+    } else {
+        // few segments, possibly one long one (an image without restart markers): the pass is a chain of steps
+        // with the two barriers of the workgroup scan each, so a thread takes four consecutive windows per step
+        for (uint32_t t0 = 0; t0 < nwin; t0 += 1024u) {
+            const uint32_t w0 = t0 + threadIdx.x * 4u;
+            uint32_t n[4], sum = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++) {
+                const uint32_t wi = w0 + j;
+                n[j] = 0;
+                if (wi < nwin) {
+                    const uint32_t q = wi / NC, c = wi - q * NC;
+                    n[j] = rec[zj_rec_index(q, c, NC, sg.lanes)] >> 16;
+                }
+                sum += n[j];
+            }
+            uint32_t total;
+            uint32_t run = carry + block_incl_scan<4>(sum, wsum, &total) - sum;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++) {
+                if (w0 + j < nwin) wb[w0 + j] = run;
+                run += n[j];
+            }
+            carry += total;
+        }
     }
     if (threadIdx.x == 0) P.seg_found[s] = carry;
 }
@@ -1082,13 +1110,15 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
         for (;;) {
             if (live) {
                 // position the reader: the column holds the 16 words from word wa on
-                uint32_t *slot = col + ((p >> 5) - wa) * 64u;
-                uint32_t w0 = slot[0], w1 = slot[64], o = p & 31u;
-                uint32_t *const last = col + (ZJ_K1W_SLOTS - 3u) * 64u; // the reader needs two words behind its own
+                // the reader's slot as a word index into the column (an index, not a pointer: pointer arithmetic
+                // in this loop is done in 64 bits)
+                uint32_t si = ((p >> 5) - wa) * 64u;
+                uint32_t w0 = col[si], w1 = col[si + 64u], o = p & 31u;
+                constexpr uint32_t last = (ZJ_K1W_SLOTS - 3u) * 64u; // the reader needs two words behind its own
                 // one symbol per turn; the loop has a single exit so that it stays one straight run of code
                 auto turn = [&](auto with_canon) -> bool {
                     const uint32_t top = (uint32_t)(((((uint64_t)w0 << 32) | w1) << o) >> 32);
-                    const uint32_t wn = slot[128];
+                    const uint32_t wn = col[si + 128u];
                     e = zj_lookup<decltype(with_canon)::value, true>(ac, cac, top);
                     const uint32_t len = (e >> 8) & 31u, sz = e & 15u;
                     z2 = z + ((e >> 4) & 15u);                 // src/decoder.rs:225
@@ -1102,16 +1132,16 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
                     const bool step = o >= 32u;
                     w0 = step ? w1 : w0;
                     w1 = step ? wn : w1;
-                    slot += step ? 64 : 0;
+                    si += step ? 64u : 0u;
                     o &= 31u;
                     live = !(eob || z2 >= 63u);                // :212, :232 (and the overflow case)
-                    return live && slot <= last;               // out of staged bits: wait for the others, then restage
+                    return live && si <= last;                 // out of staged bits: wait for the others, then restage
                 };
                 if (use_canon) { while (turn(std::true_type{})) {} }
                 else { while (turn(std::false_type{})) {} }
                 // the reader's position in bits; when the block has just ended, its last symbol was not
                 // taken off the word offset (o wraps at 32), which the slot count makes up for
-                p = (wa + (uint32_t)(slot - col) / 64u) * 32u + o;
+                p = (wa + si / 64u) * 32u + o;
             }
             if (!__any(live)) break;
             if (live) {

@@ -45,8 +45,8 @@ METRIC = "decoded megapixels/sec (whole node), 1080p 4:2:0 q90 batch; % HBM roof
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5", "c6"])
     ap.add_argument("--images", type=int, default=0, help="images per GPU (weak scaling); 0 = 4096 for c3, 8192 for c4")
     ap.add_argument("--sub-batch", type=int, default=1024, help="c4: images per sub-batch of the shared workspace")
@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--subseq-bits", type=int, default=0)
     ap.add_argument("--c5-size", type=int, default=16384, help="c5: width and height of the image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sensitivity", action="store_true", help="c3: skip the smooth and white-noise content points")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device: rehearsal of the multi-rank path on a box with a single GPU")
     ap.add_argument("--one-device", action="store_true", help="every rank uses GPU 0 (rehearsal only)")
@@ -152,24 +153,31 @@ def host_threads():
         return os.cpu_count() or 1
 
 
+STEP_MS = {}  # this rank's device milliseconds per step of the last timed region (median, min, max), from HIP events between the steps
+
+
 def timed_steps(D, stream, step, steps, warmup, check):
     """W untimed steps, then exactly K steps between barrier + synchronize on both sides; returns (max-over-ranks
-    wall seconds, this rank's device milliseconds from HIP events on the launch stream)."""
+    wall seconds, this rank's device milliseconds from HIP events on the launch stream) and leaves the per-step
+    device times in STEP_MS."""
     torch = D.torch
     for _ in range(warmup):
         step()
     check()
     D.sync_all()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(steps):
+    evs[0].record(stream)
+    for k in range(steps):
         step()
-    ev1.record(stream)
+        evs[k + 1].record(stream)
     stream.synchronize()
     D.sync_all()
     wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
+    dev_ms = evs[0].elapsed_time(evs[-1])
+    per_step = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(steps))
+    STEP_MS.clear()
+    STEP_MS.update({"median": round(per_step[len(per_step) // 2], 4), "min": round(per_step[0], 4), "max": round(per_step[-1], 4)})
     return D.max_over_ranks(wall), dev_ms
 
 
@@ -232,6 +240,33 @@ def fast_path_fields(batches):
 
 
 # ------------------------------------------------------------------------------------------ c3
+def content_point(a, ctx, stream, D, out_all, hs, vs, content, threads, nimg=1024, ndist=8):
+    """The c3 measurement on 1 024 images of another content class, decoded into the first 1 024 output buffers;
+    all distinct images are checked against the oracle."""
+    import jpeg_decoder_amd as J
+    from jpeg_decoder_amd import synth
+    with ThreadPoolExecutor(threads) as ex:
+        files = list(ex.map(lambda s: synth.encode(a.width, a.height, hs, vs, a.quality, content, 500 + s, 0), range(ndist)))
+    parsed = [J.ParsedImage(f) for f in files]
+    b = J.Batch(ctx, [parsed[i % ndist] for i in range(nimg)], a.subseq_bits)
+    tables = b.output_tables([out_all[i] for i in range(nimg)])
+
+    def check():
+        assert not b.finish().any()
+    wall, dev_ms = timed_steps(D, stream, lambda: b.decode(tables), 5, 2, check)
+    check()
+    fast = fast_path_fields([b])
+    nver, bad = verify_against_oracle(files, lambda k: (out_all[k][:, : a.width * 3].reshape(a.height, a.width, 3).cpu().numpy(),
+                                                        b.coefficients(k)), threads)
+    assert not bad and not any(fast.values()), f"content class {content}: mismatches {bad}, fast path {fast}"
+    bc = b.byte_counts()
+    b.close()
+    return {"value": round(bc["pixels"] / (dev_ms / 5 * 1e-3) / 1e6, 1), "unit": "MP/s", "images": nimg,
+            "scan_bytes_per_pixel": round(bc["scan"] / bc["pixels"], 4), "ms_per_step": round(dev_ms / 5, 3),
+            "roofline_end_to_end_frac": round((bc["scan"] + 2 * bc["coef"] + bc["rgb"]) / (dev_ms / 5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "distinct_images_checked": nver}
+
+
 def run_c3(a, D):
     import numpy as np
     import jpeg_decoder_amd as J
@@ -287,6 +322,7 @@ def run_c3(a, D):
             "roofline": roofline_fields(kt, S, Cb, P, f"c3:{nimg}" if a.sampling == "420" and a.content == 0 else None),
             "roofline_end_to_end": {"achieved": round(e2e, 1), "unit": "GB/s", "frac": round(e2e / HBM_PEAK_GBS, 4),
                                     "algorithmic_bytes_per_step": S + 2 * Cb + P, "device_ms_per_step": round(dev_ms / a.steps, 3)},
+            "step_device_ms": dict(STEP_MS),
             "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
             "verified_vs_oracle": {"distinct_images_checked": nver, "mismatches": len(bad), "copies_equal_their_source": bool(copies_equal)},
             "fast_path": fast,
@@ -296,6 +332,10 @@ def run_c3(a, D):
             result["cpu_baseline"] = cpu_baseline(files, a.width * a.height, a.cpu_sample, threads,
                                                   f"of the benchmark's {a.width}x{a.height} images")
     batch.close()
+    if D.rank == 0 and D.world == 1 and nimg >= 1024 and a.content == 0 and not a.no_sensitivity:
+        # the two other content classes as sensitivity points: a smooth image (few bits per block) and white noise
+        result["content_sensitivity"] = {name: content_point(a, ctx, stream, D, out_all, hs, vs, c, threads)
+                                         for name, c in (("smooth", 1), ("white_noise", 2))}
     h2h = a.h2h_sample if a.h2h_sample >= 0 else (1024 if (D.world == 1 and nimg >= 1024) else 0)
     if D.rank == 0 and D.world == 1 and h2h > 0:
         del out_all, outs, tables
@@ -408,7 +448,7 @@ def run_c2(a, D):
         crc = zlib.crc32(np.ascontiguousarray(outs[0][:, : p.width * 3].cpu().numpy()).tobytes())
         ok = crc == info[name]["rgb_crc"] and zlib.crc32(b.coefficients(0).tobytes()) == info[name]["qcoef_crc"]
         res[name] = {"pixels": p.width * p.height, "ms": round(dev_ms / a.steps, 4), "wall_ms": round(wall / a.steps * 1e3, 4),
-                     "kernel_ms": {k: round(v, 4) for k, v in kt.items()}, "equals_committed_oracle_hashes": bool(ok),
+                     "step_device_ms": dict(STEP_MS), "kernel_ms": {k: round(v, 4) for k, v in kt.items()}, "equals_committed_oracle_hashes": bool(ok),
                      "fast_path": fast_path_fields([b]),
                      "roofline_end_to_end_frac": round((bc["scan"] + 2 * bc["coef"] + bc["rgb"]) / (dev_ms / a.steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if name == "large.jpg":
@@ -524,7 +564,7 @@ def run_c4(a, D):
             "roofline": roofline_fields(kt, S, Cb, P),
             "roofline_end_to_end": {"achieved": round(e2e, 1), "unit": "GB/s", "frac": round(e2e / HBM_PEAK_GBS, 4),
                                     "algorithmic_bytes_per_step_all_ranks": bytes_all, "device_ms_per_step": round(dev_ms / a.steps, 3)},
-            "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
+            "step_device_ms": dict(STEP_MS), "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
             "verified_vs_oracle": {"distinct_images_checked_on_rank0": nver, "mismatches_on_rank0": len(bad), "all_ranks_ok": bool(ok)},
             "fast_path": fast,
         }
@@ -635,7 +675,7 @@ def run_c5(a, D, restart_free=False):
             "roofline_end_to_end": {"achieved": round(e2e_band, 1), "unit": "GB/s", "frac": round(e2e_band / HBM_PEAK_GBS, 4),
                                     "algorithmic_bytes_per_step_rank0_band": S + 2 * Cb + P, "device_ms_per_step": round(dev_ms / a.steps, 3),
                                     "note": "rank 0's band and its stream time, which includes waiting for the gather"},
-            "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
+            "step_device_ms": dict(STEP_MS), "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
             "verified": {"crc32_gathered": crc_gathered, "crc32_whole_image_one_gpu": crc_whole, "equal": crc_gathered == crc_whole,
                          "equals_oracle": bool(strips_ok)},
             "fast_path": fast,

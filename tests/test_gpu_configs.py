@@ -188,3 +188,11 @@ def test_rows_of_images_without_restart_markers(ctx):
         y0 = r[0] * mh if r and r[1] else 0
         assert np.array_equal(o[:, : im.width * 3].reshape(-1, im.width, 3).cpu().numpy(), ref[y0: y0 + b.window_height(i)]), i
     b.close()
+
+
+def test_random_images_match_the_oracle(ctx):
+    """Three batches of the randomised sweep (tests/sweep_parity.py): 64 random valid images each -- sizes, sampling
+    layouts, qualities, content classes, restart intervals, table ids -- decoded with two subsequence sizes."""
+    import sweep_parity
+    total, bad, _ = sweep_parity.run(3, 11, ctx=ctx, verbose=False)
+    assert total == 3 * 64 * 2 and bad == 0

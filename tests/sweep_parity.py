@@ -19,17 +19,17 @@ LAYOUTS = [(0, 0), (1, 1), (2, 1), (1, 2), (2, 2)]
 RI = [0, 0, 0, 1, 2, 3, 7, 16, 50, 500]
 
 
-def run(nbatches, seed, ctx=None, verbose=True):
+def run(nbatches, seed, ctx=None, verbose=True, scale=1, per_batch=64):
     """Returns (decodes checked, mismatches, batches that left the fast path)."""
     rng = np.random.default_rng(seed)
     ctx = ctx or J.Context(0)
     bad = total = slow = 0
     for rnd in range(nbatches):
         specs = []
-        for _ in range(64):
+        for _ in range(per_batch):
             big = rng.integers(0, 4) == 0
-            w = int(rng.integers(1, 700 if big else 120))
-            h = int(rng.integers(1, 700 if big else 120))
+            w = int(rng.integers(1, (700 if big else 120) * scale))
+            h = int(rng.integers(1, (700 if big else 120) * scale))
             hs, vs = LAYOUTS[int(rng.integers(0, 5))]
             content = int(rng.integers(0, 3)) + (int(rng.integers(0, 8)) << 8 if hs else 0)
             specs.append((w, h, hs, vs, int(rng.integers(30, 99)), content, int(rng.integers(0, 1 << 30)), RI[int(rng.integers(0, len(RI)))]))
@@ -60,6 +60,8 @@ def run(nbatches, seed, ctx=None, verbose=True):
 
 
 if __name__ == "__main__":
-    total, bad, slow = run(int(sys.argv[1]) if len(sys.argv) > 1 else 10, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    # python tests/sweep_parity.py [batches] [seed] [size scale] [images per batch]
+    total, bad, slow = run(int(sys.argv[1]) if len(sys.argv) > 1 else 10, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+                           scale=int(sys.argv[3]) if len(sys.argv) > 3 else 1, per_batch=int(sys.argv[4]) if len(sys.argv) > 4 else 64)
     print("done", total, "mismatches", bad, "batches off the fast path", slow)
     sys.exit(1 if bad else 0)

@@ -81,6 +81,9 @@ extern "C" {
     pub fn zj_batch_create(ctx: *mut ZjCtx, imgs: *const ZjImage, n: usize, flags: u32) -> *mut ZjBatch;
     pub fn zj_batch_destroy(b: *mut ZjBatch);
     pub fn zj_batch_decode(b: *mut ZjBatch, rgb: *const *mut u8, stride: *const usize) -> c_int;
+    // the two halves of zj_batch_decode; `stream` = NULL for the context's stream
+    pub fn zj_batch_decode_entropy(b: *mut ZjBatch) -> c_int;
+    pub fn zj_batch_decode_pixels(b: *mut ZjBatch, rgb: *const *mut u8, stride: *const usize, stream: *mut c_void) -> c_int;
     pub fn zj_batch_finish(b: *mut ZjBatch, status: *mut u32) -> c_int;
     pub fn zj_batch_counters(b: *mut ZjBatch, counters: *mut u32) -> c_int;
     pub fn zj_batch_export_coef(b: *mut ZjBatch, i: usize, qcoef: *mut i16, dqcoef: *mut i16, mem: c_int) -> c_int;
@@ -90,6 +93,7 @@ extern "C" {
     pub fn zj_workspace_create(ctx: *mut ZjCtx, scratch_bytes: usize, plan_bytes: usize, nslots: u32) -> *mut ZjWorkspace;
     pub fn zj_workspace_destroy(ws: *mut ZjWorkspace);
     pub fn zj_batch_create_in(ws: *mut ZjWorkspace, slot: u32, imgs: *const ZjImage, n: usize, flags: u32) -> *mut ZjBatch;
+    pub fn zj_batch_create_rows(ctx: *mut ZjCtx, imgs: *const ZjImage, n: usize, flags: u32, row0: *const u32, nrows: *const u32) -> *mut ZjBatch;
 
     // One restart-marked image cut into bands (one per GPU).
     pub fn zj_restart_offsets(img: *const ZjImage, offsets: *mut usize, cap: usize) -> usize;

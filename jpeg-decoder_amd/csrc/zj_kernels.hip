@@ -705,7 +705,68 @@ __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
     const uint32_t *rec = P.winfo + sg.first_win;
     uint32_t *wb = P.wbase + sg.first_win;
     uint32_t carry = 0;
-    if (P.nseg >= 256u) {
+    if (P.nseg >= 256u && sg.lanes == 64u && sg.nsub <= 128u) {
+        // Enough segments to fill the GPU, and one or two whole chunks of 64 subsequences (a longer segment is a longer
+        // chain of tiles than of the plain steps below): the records lie [chunk][window of
+        // the subsequence][lane] while the result goes out in stream order [lane][window], so a chunk is taken in
+        // tiles of 64 windows x 64 lanes through LDS, with the reads and the writes both along their own layout.
+        __shared__ uint32_t tl[64 * 65];
+        __shared__ uint32_t lane_base[64], part_sum[256];
+        __shared__ uint32_t chunk_total;
+        const uint32_t lane = threadIdx.x & 63u, part = threadIdx.x >> 6;
+        for (uint32_t k = 0; k < (sg.nsub + 63u) / 64u; k++) { // the last chunk may have lanes without a subsequence: their windows lie behind nwin
+            const uint32_t *rk = rec + (size_t)k * NC * 64u;
+            const uint32_t w_lane = (k * 64u + lane) * NC; // first window of this thread's lane, in stream order
+            uint32_t sum = 0;
+            for (uint32_t c = part; c < NC; c += 4u)
+                if (w_lane + c < nwin) sum += rk[c * 64u + lane] >> 16;
+            tl[part * 64u + lane] = sum;
+            __syncthreads();
+            if (threadIdx.x < 64u) {
+                const uint32_t t = tl[lane] + tl[64u + lane] + tl[128u + lane] + tl[192u + lane];
+                const uint32_t inc = wave_incl_scan(t, lane);
+                lane_base[lane] = carry + inc - t; // blocks that begin before this lane's subsequence
+                if (lane == 63u) chunk_total = inc;
+            }
+            __syncthreads();
+            for (uint32_t c0 = 0; c0 < NC; c0 += 64u) {
+#pragma unroll 4
+                for (uint32_t i = 0; i < 16u; i++) {
+                    const uint32_t cl = part * 16u + i, c = c0 + cl;
+                    tl[cl * 65u + lane] = (c < NC && w_lane + c < nwin) ? rk[c * 64u + lane] >> 16 : 0u;
+                }
+                __syncthreads();
+                {
+                    // the running count along a lane's 64 windows, in four stretches of 16: every thread adds up its
+                    // stretch, learns what the stretches before it hold, and walks its stretch again with the count
+                    uint32_t mine = 0;
+#pragma unroll 4
+                    for (uint32_t j = 0; j < 16u; j++) mine += tl[(part * 16u + j) * 65u + lane];
+                    part_sum[part * 64u + lane] = mine;
+                    __syncthreads();
+                    uint32_t run = lane_base[lane];
+                    for (uint32_t q = 0; q < part; q++) run += part_sum[q * 64u + lane];
+#pragma unroll 4
+                    for (uint32_t j = 0; j < 16u; j++) {
+                        const uint32_t v = tl[(part * 16u + j) * 65u + lane];
+                        tl[(part * 16u + j) * 65u + lane] = run;
+                        run += v;
+                    }
+                    __syncthreads(); // every thread has read lane_base
+                    if (part == 3u) lane_base[lane] = run;
+                }
+                __syncthreads();
+#pragma unroll 4
+                for (uint32_t i = 0; i < 16u; i++) {
+                    const uint32_t l = part + 4u * i, c = c0 + lane; // here a thread's low bits run along the windows
+                    const uint32_t wi = (k * 64u + l) * NC + c;
+                    if (c < NC && wi < nwin) wb[wi] = tl[lane * 65u + l];
+                }
+                __syncthreads();
+            }
+            carry += chunk_total;
+        }
+    } else if (P.nseg >= 256u) {
         // enough segments to fill the GPU: one window per thread and step, neighbouring threads read neighbouring records
         for (uint32_t t0 = 0; t0 < nwin; t0 += 256u) {
             const uint32_t wi = t0 + threadIdx.x;

@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 IMAGES=${IMAGES:-256}
 # ARGS_OVERRIDE replaces the default c3 arguments (e.g. "--config c5 --steps 1 --warmup 1 --no-cpu-baseline")
-ARGS=${ARGS_OVERRIDE:-"--images $IMAGES --steps 1 --warmup 1 --no-cpu-baseline --h2h-sample 0 $*"}
+ARGS=${ARGS_OVERRIDE:-"--images $IMAGES --steps 1 --warmup 1 --no-cpu-baseline --no-sensitivity --h2h-sample 0 $*"}
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -3 "$OUT/trace.log"; exit 1; }
 pass() {

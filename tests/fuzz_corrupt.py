@@ -1,6 +1,7 @@
-"""One-off robustness run: corrupted entropy data must produce status bits, never a fault or a hang."""
+"""Robustness run on the GPU (by hand: python tests/fuzz_corrupt.py; not collected by pytest): corrupted entropy data must
+produce status bits, never a fault or a hang."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import jpeg_decoder_amd as J

@@ -459,7 +459,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     // MCUs per wavefront of the write pass: 32 (64 for 4:4:4) times a power of two up to 8, as long as the batch
     // still gives every CU several sets of wavefronts (measured: x8 is 7 % faster than x1 on a large batch).
     uint32_t k1w_mult = 1;
-    while (k1w_mult < 8u && mcus_total / (64u * k1w_mult) >= (uint64_t)cus * 12u * 4u) k1w_mult *= 2u;
+    while (k1w_mult < 16u && mcus_total / (64u * k1w_mult) >= (uint64_t)cus * 12u * 4u) k1w_mult *= 2u;
     // Strips per workgroup of the IDCT/colour kernel: 4, doubled up to 16 while the batch keeps every CU
     // supplied with workgroups (a strip is about 16 MCUs; measured: 16 is 4 % faster than 4 on a large batch).
     uint32_t k2_ns = ZJ_K2_NS;

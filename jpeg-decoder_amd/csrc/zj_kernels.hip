@@ -920,15 +920,42 @@ __device__ __forceinline__ ZjDcTile zj_dc_tile_load(const int16_t *da, uint32_t 
 #pragma unroll
     for (uint32_t cc = 0; cc < 3u; cc++) t.loc[cc] = 0;
 #pragma unroll
+    for (uint32_t k = 0; k < 6u; k++) t.d[k] = 0;
+    if (bpm == 6u && (reinterpret_cast<uintptr_t>(da) & 3u) == 0) {
+        // six blocks per MCU: a lane's twelve bytes in three word loads instead of six halfword loads
+        if (m < nmcu) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(da + m * 6u);
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            t.d[0] = (uint32_t)(int32_t)(int16_t)w0; t.d[1] = (uint32_t)((int32_t)w0 >> 16);
+            t.d[2] = (uint32_t)(int32_t)(int16_t)w1; t.d[3] = (uint32_t)((int32_t)w1 >> 16);
+            t.d[4] = (uint32_t)(int32_t)(int16_t)w2; t.d[5] = (uint32_t)((int32_t)w2 >> 16);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 6u; k++)
+            if (k < bpm && m < nmcu) t.d[k] = (uint32_t)(int32_t)da[m * bpm + k];
+    }
+#pragma unroll
     for (uint32_t k = 0; k < 6u; k++) {
-        t.d[k] = 0;
-        if (k < bpm && m < nmcu) t.d[k] = (uint32_t)(int32_t)da[m * bpm + k];
         const uint32_t c = (compsel >> (2u * k)) & 3u;
 #pragma unroll
         for (uint32_t cc = 0; cc < 3u; cc++)
             if (c == cc && k < bpm) t.loc[cc] += t.d[k];
     }
     return t;
+}
+
+__device__ __forceinline__ void zj_dc_tile_store(int16_t *da, uint32_t m, uint32_t nmcu, uint32_t bpm, const uint32_t (&v)[6])
+{
+    if (m >= nmcu) return;
+    if (bpm == 6u && (reinterpret_cast<uintptr_t>(da) & 3u) == 0) {
+        uint32_t *w = reinterpret_cast<uint32_t *>(da + m * 6u);
+        w[0] = v[0] | (v[1] << 16); w[1] = v[2] | (v[3] << 16); w[2] = v[4] | (v[5] << 16);
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 6u; k++)
+            if (k < bpm) da[m * bpm + k] = (int16_t)v[k];
+    }
 }
 
 __global__ __launch_bounds__(256) void zj_k1d_tilesum(ZjParams P)
@@ -989,6 +1016,7 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan(ZjParams P)
         const uint32_t inc = block_incl_scan<4>(t.loc[cc], wsum, &total);
         run[cc] = before + inc - t.loc[cc];
     }
+    uint32_t out[6];
 #pragma unroll
     for (uint32_t k = 0; k < 6u; k++) {
         const uint32_t c = (compsel >> (2u * k)) & 3u;
@@ -996,8 +1024,9 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan(ZjParams P)
 #pragma unroll
         for (uint32_t cc = 0; cc < 3u; cc++)
             if (c == cc && k < bpm) { run[cc] += t.d[k]; v = run[cc]; }
-        if (k < bpm && m < nmcu) da[m * bpm + k] = (int16_t)v;
+        out[k] = v & 0xFFFFu;
     }
+    zj_dc_tile_store(da, m, nmcu, bpm, out);
 }
 
 // The same for segments of at most 64 MCUs (short restart intervals), which the planner lists apart: one
@@ -1017,6 +1046,7 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan_small(ZjParams P, uint32_t 
     uint32_t run[3];
 #pragma unroll
     for (uint32_t cc = 0; cc < 3u; cc++) run[cc] = wave_incl_scan(t.loc[cc], lane) - t.loc[cc];
+    uint32_t out[6];
 #pragma unroll
     for (uint32_t k = 0; k < 6u; k++) {
         const uint32_t c = (compsel >> (2u * k)) & 3u;
@@ -1024,8 +1054,9 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan_small(ZjParams P, uint32_t 
 #pragma unroll
         for (uint32_t cc = 0; cc < 3u; cc++)
             if (c == cc && k < bpm) { run[cc] += t.d[k]; v = run[cc]; }
-        if (k < bpm && lane < nmcu) da[lane * bpm + k] = (int16_t)v;
+        out[k] = v & 0xFFFFu;
     }
+    zj_dc_tile_store(da, lane, nmcu, bpm, out);
 }
 
 // ---------------------------------------------------------------------------------- k1w: write

@@ -464,6 +464,9 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     // supplied with workgroups (a strip is about 16 MCUs; measured: 16 is 4 % faster than 4 on a large batch).
     uint32_t k2_ns = ZJ_K2_NS;
     while (k2_ns < 16u && mcus_total / 16u / (k2_ns * 2u) >= (uint64_t)cus * 16u) k2_ns *= 2u;
+#ifdef ZJ_K2_NS_FORCE // experiments only (tools/exp/build_variant.sh)
+    k2_ns = ZJ_K2_NS_FORCE;
+#endif
     b->P.k2_ns = k2_ns;
     for (size_t i = 0; i < n; i++) {
         const zj_image &im = images[i];
@@ -713,9 +716,25 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     }
     for (size_t i = 0; i < n; i++)
         if (b->imgs[i].flags && pair_needs_canon[b->imgs[i].lut_set]) b->imgs[i].flags |= 4u;
+    // the AC tables (third and fourth of a set) as write entries: in the direct form when their long codes fit it
+    // (and the testing aid that drops the second level is off), else in the layout of the 16-bit tables
+    const size_t nsets = luts.size() / ZJ_SET_ENTRIES;
+    std::vector<uint32_t> wtabs(nsets * 2u * ZJ_WT_ENTRIES, 0u), wt_info(nsets * 2u + 2u, ZJ_WT_TWO_LEVEL);
+    for (size_t set = 0; set < nsets; set++)
+        for (uint32_t t = 0; t < 2u; t++) {
+            uint32_t *wt = &wtabs[(set * 2u + t) * ZJ_WT_ENTRIES];
+            const ZjCanon &cn = canons[set * 4u + 2u + t];
+#ifndef ZJ_V_NODIRECT // experiments only
+            if (l2_cap != 0 && cn.nsym != 0 && zj_build_direct_table(&cn, wt, &wt_info[set * 2u + t])) continue;
+#endif
+            wt_info[set * 2u + t] = ZJ_WT_TWO_LEVEL;
+            for (uint32_t e = 0; e < ZJ_TBL_ENTRIES; e++) wt[e] = zj_write_entry(luts[set * ZJ_SET_ENTRIES + (2u + t) * ZJ_TBL_ENTRIES + e]);
+        }
     P.luts = dev_upload(b, luts);
     P.wluts = dev_upload(b, wluts);
     P.ptabs = dev_upload(b, ptabs);
+    P.wtabs = dev_upload(b, wtabs);
+    P.wt_info = dev_upload(b, wt_info);
     P.imgs = dev_upload(b, b->imgs); // after the table forms are known: the descriptors carry their flags
     P.canons = dev_upload(b, canons);
     P.qts = dev_upload(b, qts);
@@ -724,7 +743,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     P.flags = dev_alloc<uint32_t>(b, 4, true);
     b->d_rgb = dev_alloc<uint8_t *>(b, n, true);
     b->d_stride = dev_alloc<size_t>(b, n, true);
-    ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.wluts && P.ptabs && P.canons && P.qts &&
+    ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.wluts && P.ptabs && P.wtabs && P.wt_info && P.canons && P.qts &&
          P.ptile_seg && P.tile_seg && P.dtile_seg && P.status && P.flags && b->d_rgb && b->d_stride;
     if (ok && mode == ZJ_ALLOC_NONE) {
         // the rest of the range is this call's scratch
@@ -820,7 +839,7 @@ extern "C" int zj_workspace_estimate(const zj_image *images, size_t n, size_t *p
         const uint64_t utiles = len / ZJ_UNSTUFF_TILE + 2 * S, ptiles = win / 256 + S, dtiles = M / 256 + S;
         const uint64_t mtiles = len / ZJ_MARK_TILE + 1;
         plan += align_up((size_t)len, 16) + 16 + S * sizeof(ZjSegDev) + 4 * (chunks + B / 256 + (M / 128 + 1) + ptiles + utiles + dtiles) + 8 * (M / 16 + 2);
-        plan += 2 * ZJ_SET_ENTRIES * 2 + ZJ_PSET_ENTRIES * 4 + 4 * sizeof(ZjCanon) + 3 * 64 * 2;  // a table set (three forms) and quantisation tables of its own
+        plan += 2 * ZJ_SET_ENTRIES * 2 + ZJ_PSET_ENTRIES * 4 + 2 * ZJ_WT_ENTRIES * 4 + 512 + 4 * sizeof(ZjCanon) + 3 * 64 * 2;  // a table set (four forms) and quantisation tables of its own
         plan += sizeof(ZjMarkImg) + 8 * mtiles + 4 + 4 * (S + 1);           // restart-marker search
         scr += 16 * dtiles + 8 * (utiles + S) + 2 * (len + 112 * S) + 8 * S + 8 * win + 7 * B + 128 * B;
     }

@@ -60,6 +60,26 @@
 #define ZJ_PT_ENTRIES (ZJ_PL1_SIZE + ZJ_PL2_SIZE)
 #define ZJ_PSET_ENTRIES (4 * ZJ_PT_ENTRIES)
 
+// The write pass, which turns every AC symbol into a coefficient, uses a fourth form of the AC tables ("write
+// entries"): ZJ_TBL_ENTRIES uint32 entries per table, laid out like the 16-bit form, whose fields are whole bytes so
+// that the kernel's arithmetic can pick them up as operands without extracting them first.
+//   entry, bit 31 clear:  byte 0  bits of the symbol, code and value (0 for a bit pattern that is no code)
+//                         byte 1  code length (0: no such code)
+//                         byte 2  zig-zag advance: run + 1, or 64 for an EOB and for a pattern that is no code
+//                                 (either ends the block)
+//                         byte 3  31 - size of the value (16..31)
+//   entry, bit 31 set  :  first level only: [26:24] nb, [8:0] sub-table offset, as in the 16-bit form
+#define ZJ_WE_START ((1u << 8) | (64u << 16) | (31u << 24)) // what a lane holds before its first symbol: a valid code that ended a block
+// A table whose long codes are few enough is stored in a second, "direct" form that needs one lookup for every code
+// (canonical codes grow with their length, so all codes longer than the first level lie above the short ones): with
+// t16 = the first code longer than ZJ_L1_BITS bits, left-aligned in 16 bits (a multiple of 128; 0x10000 when there is
+// none), the entry for the next 16 bits x of the stream is at index (x >> 7) + max(0, x - t16) -- the first level for
+// x < t16, and behind it one entry per 16-bit value, which begins in the first-level slots of the long prefixes.  The
+// form is used when 512 + 0x10000 - t16 <= ZJ_WT_ENTRIES (the Annex K tables need 1152 entries); otherwise the write
+// entries stay in the two-level layout (ZJ_WT_TWO_LEVEL in place of t16).
+#define ZJ_WT_ENTRIES 1280
+#define ZJ_WT_TWO_LEVEL 0xFFFFFFFFu
+
 // Canonical description of one table, used by the rare fallback path only.
 struct ZjCanon {
     uint16_t ncode[17];   // number of codes of length l (index 1..16)
@@ -355,6 +375,16 @@ ZJ_HD uint32_t zj_walk_entry(uint32_t e, bool isdc)
     const uint32_t sbits = isdc ? (sym > 16u ? 16u : sym) : (sym & 15u);
     const uint32_t zadv = isdc ? 1u : (sym == 0 ? 64u : (sym >> 4) + 1u);
     return (len + sbits) | (zadv << 6);
+}
+
+// Write entry of a 16-bit AC table entry (first-level pointers keep their fields).
+ZJ_HD uint32_t zj_write_entry(uint32_t e)
+{
+    if (e & 0x8000u) return 0x80000000u | (((e >> 12) & 7u) << 24) | (e & 0x1FFu);
+    const uint32_t len = (e >> 8) & 31u, sym = e & 255u;
+    if (len == 0) return (64u << 16) | (31u << 24);
+    const uint32_t size = sym & 15u, zadv = sym == 0 ? 64u : (sym >> 4) + 1u;
+    return (len + size) | (len << 8) | (zadv << 16) | ((31u - size) << 24);
 }
 
 // First-level entry for the next bits of the stream.  LDS = true says the table is in LDS (kernels only):

@@ -42,6 +42,8 @@ struct ZjParams {
     const uint16_t *luts;       // [table set][ZJ_SET_ENTRIES]
     const uint16_t *wluts;      // the same sets as walk entries
     const uint32_t *ptabs;      // the same sets as pair entries, [table set][ZJ_PSET_ENTRIES]
+    const uint32_t *wtabs;      // the AC tables of the same sets as write entries, [table set][2][ZJ_WT_ENTRIES]
+    const uint32_t *wt_info;    // [table set][2] form of those tables: the direct form's t16, or ZJ_WT_TWO_LEVEL
     const ZjCanon *canons;      // [table set][4]
     const uint16_t *qts;        // quantisation tables widened to 16 bits, 64 entries each, zig-zag order
     const uint32_t *blk256_img; // [block / 256] image

@@ -310,6 +310,32 @@ bool zj_build_table(const zj_huff *h, uint16_t *tbl, ZjCanon *canon, uint32_t l2
     return true;
 }
 
+// Write entries of an AC table in the direct form (zj_core.h, ZJ_WT_ENTRIES): returns false when the codes longer than
+// the first level take more room than the form has, and the caller keeps the two-level layout.
+bool zj_build_direct_table(const ZjCanon *canon, uint32_t *wt, uint32_t *t16)
+{
+    uint32_t first_long = 0x10000u;
+    for (uint32_t l = ZJ_L1_BITS + 1; l <= 16 && first_long == 0x10000u; l++)
+        if (canon->ncode[l]) first_long = (uint32_t)canon->mincode[l] << (16 - l);
+    if (first_long != 0x10000u && ((first_long & 127u) != 0 || (0xFFFFu >> 7) + (0xFFFFu - first_long) >= ZJ_WT_ENTRIES)) return false;
+    const uint32_t none = zj_write_entry(0);
+    for (uint32_t i = 0; i < ZJ_WT_ENTRIES; i++) wt[i] = none;
+    for (uint32_t l = 1; l <= 16; l++) {
+        for (uint32_t i = 0; i < canon->ncode[l]; i++) {
+            const uint32_t code = (uint32_t)canon->mincode[l] + i, sym = canon->symbols[(canon->valptr[l] + i) & 255u];
+            const uint32_t entry = zj_write_entry((l << 8) | sym);
+            const uint32_t x0 = code << (16 - l), nx = 1u << (16 - l); // the 16-bit values that begin with this code
+            if (l <= ZJ_L1_BITS) {
+                for (uint32_t x = x0; x < x0 + nx; x += 128u) wt[x >> 7] = entry;
+            } else {
+                for (uint32_t x = x0; x < x0 + nx; x++) wt[(x >> 7) + (x - first_long)] = entry;
+            }
+        }
+    }
+    *t16 = first_long;
+    return true;
+}
+
 // The same table in walk-entry form (zj_core.h): long first-level entries keep their sub-table
 // reference, every other entry turns into (bits to consume, zig-zag advance).
 void zj_build_walk_table(const uint16_t *tbl, bool isdc, uint16_t *wtbl)

@@ -18,3 +18,7 @@ void zj_build_walk_table(const uint16_t *tbl, bool isdc, uint16_t *wtbl);
 // description from zj_build_table.  Returns false when the long codes do not fit the second level; the
 // first-level entries of long prefixes then send the walk to the canonical search.
 bool zj_build_pair_table(const ZjCanon *canon, bool isdc, uint32_t *ptbl);
+
+// The AC table in the direct form of its write entries (zj_core.h): ZJ_WT_ENTRIES entries and the form's parameter.
+// Returns false when the table's long codes do not fit; `wt` is then undefined.
+bool zj_build_direct_table(const ZjCanon *canon, uint32_t *wt, uint32_t *t16);

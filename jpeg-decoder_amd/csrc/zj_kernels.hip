@@ -1066,40 +1066,181 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan_small(ZjParams P, uint32_t 
 // decodes its block into a private 132-byte row of an LDS tile (a row pitch of 33 words keeps lanes
 // on distinct banks while they write the same zig-zag index); then the wavefront stores the 64 rows,
 // eight lanes per block, one full 128-byte line per block.
-// The block's bits are staged in a private LDS column of 16 words (the 64 bytes that hold the block's
-// first bit, fetched a round ahead), read with the same branch-free two-word reader as the sync pass;
-// a block that outgrows its column waits for the others and is restaged.  The DC symbol is not decoded
-// again: its length comes from the DC pass.
+// The block's bits are staged in a private LDS column of 14 words (from the word that holds the block's
+// first bit, fetched a round ahead), read with a branch-free two-word reader; a block that outgrows its
+// column waits for the others and is restaged.  The DC symbol is not decoded again: its length comes from
+// the DC pass.
 // MCUs per wavefront: chosen by the planner, a multiple of 64 for 4:4:4 and of 32 otherwise (whole rounds);
 // long runs amortise a wavefront's start (tables into LDS, two dependent trips to memory before the first symbol).
-#define ZJ_K1W_SLOTS 16u
+#ifndef ZJ_K1W_SLOTS
+#define ZJ_K1W_SLOTS 14u
+#endif
+typedef uint32_t zj_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4))); // sixteen bytes at any word address
+typedef uint32_t zj_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+__device__ __forceinline__ uint32_t zj_lds_addr(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p; }
+
+// The AC symbols of one block (src/decoder.rs:208-235), one per turn of the loop, for the lanes that are active on
+// entry.  State of a lane: w0, w1 = the stream word that holds the current bit and the one behind it (MSB first);
+// r = 32 minus the bits of w0 that are used up (0..31: r = 0 says all of w0 is used up and the reader has not yet moved
+// on, so that the next 32 bits are always ({w0, w1} >> r), one v_alignbit_b32); si = LDS address of w0's slot in the
+// lane's column (pitch 256 bytes); z = zig-zag index of the next coefficient (1..63; 64 and more: the block has ended);
+// e = the last symbol's write entry (zj_write_entry).  A lane leaves the loop when its block has ended or when the
+// word after w1 would lie behind slot `last`.
+// Written in assembly: the compiler's version of the same loop (zj_k1w_symbols_ref) takes 31 vector and 14 scalar
+// instructions per symbol and, for a long code, a second trip to LDS that depends on the first; this one takes 24 and 3
+// with the table in its direct form (one lookup whatever the code length), 22 and 4 plus the second trip in the
+// two-level form.  The fields of an entry are whole bytes that the arithmetic picks up through SDWA operand selects,
+// the borrow of the bit count moves the reader on, and the loop mask is one s_and.
+// The value of a symbol is worked out one turn late, while the next symbol's table entry is on its way from LDS:
+// x = its value bits (on top of the word), e = its entry, a = where its coefficient goes.
+#define ZJ_K1W_SDWA(s0, s1) " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" s0 " src1_sel:" s1 "\n\t"
+// EXTEND of the symbol before (src/ec.rs:52-59): with b = leading value bit, the value is the (size + 1)-bit number
+// (~b, value bits) sign-extended, plus 1 - b
+#define ZJ_K1W_VALUE                                                                                                   \
+    "v_lshrrev_b32_e32 %[v], 1, %[x]\n\t"                                                                              \
+    "v_bitop3_b32 %[v], %[v], %[x], %[k80] bitop3:0xf2\n\t" /* (x >> 1) | (~x & 0x80000000) */                         \
+    "v_ashrrev_i32_sdwa %[v], %[e], %[v]" ZJ_K1W_SDWA("BYTE_3", "DWORD") /* >> (31 - size) */                          \
+    "v_ashrrev_i32_e32 %[u], 31, %[x]\n\t"                                                                             \
+    "v_add3_u32 %[v], %[v], %[u], 1\n\t"                                                                               \
+    "ds_write_b16 %[a], %[v]\n\t"
+// what follows the arrival of the entry e2 and of wn, the word after w1
+#define ZJ_K1W_STEP                                                                                                    \
+    "v_sub_co_u32_sdwa %[r], vcc, %[r], %[e2]" ZJ_K1W_SDWA("DWORD", "BYTE_0") /* r -= bits of the symbol */            \
+    "v_cndmask_b32_e32 %[w0], %[w0], %[w1], vcc\n\t"                          /* a borrow moves the reader on */       \
+    "v_cndmask_b32_e32 %[w1], %[w1], %[wn], vcc\n\t"                                                                   \
+    "v_cndmask_b32_e64 %[t], 0, 1, vcc\n\t"                                                                            \
+    "v_lshl_add_u32 %[si], %[t], 8, %[si]\n\t"                                                                         \
+    "v_and_b32_e32 %[r], 31, %[r]\n\t"                                                                                 \
+    "v_lshlrev_b32_sdwa %[x], %[e2], %[top]" ZJ_K1W_SDWA("BYTE_1", "DWORD") /* value bits on top */                    \
+    "v_add_u32_sdwa %[z], %[z], %[e2]" ZJ_K1W_SDWA("DWORD", "BYTE_2")       /* z += run + 1 */                         \
+    "v_min_u32_e32 %[t], 0x41, %[z]\n\t"                                    /* index z - 1, or the spare slot 64 */    \
+    "v_lshl_add_u32 %[a], %[t], 1, %[rowm2]\n\t"                                                                       \
+    "v_mov_b32_e32 %[e], %[e2]\n\t"                                                                                    \
+    "v_cmp_gt_u32_e32 vcc, 64, %[z]\n\t"                /* the block goes on */                                        \
+    "v_cmp_ge_u32_e64 %[s1], %[last], %[si]\n\t"        /* and the column holds the words of the next turn */          \
+    "s_and_b64 exec, vcc, %[s1]\n\t"                                                                                   \
+    "s_cbranch_scc1 1b\n\t"                                                                                            \
+    "s_mov_b64 exec, %[sx]\n\t"
+#define ZJ_K1W_OPERANDS                                                                                                \
+    : [w0] "+v"(w0), [w1] "+v"(w1), [r] "+v"(r), [si] "+v"(si), [z] "+v"(z), [e] "+v"(e), [x] "+v"(x), [a] "+v"(a), [top] "=&v"(top),   \
+      [t] "=&v"(t), [u] "=&v"(u), [e2] "=&v"(e2), [wn] "=&v"(wn), [v] "=&v"(v), [sx] "=&s"(sx), [s1] "=&s"(s1)
+
+// Two-level form of the table: first level of ZJ_L1_BITS bits, sub-tables behind it (zj_write_entry).
+__device__ __forceinline__ void zj_k1w_symbols(uint32_t &w0, uint32_t &w1, uint32_t &r, uint32_t &si, uint32_t &z, uint32_t &e,
+                                               uint32_t lut, uint32_t rowm2, uint32_t last)
+{
+    uint32_t top, t, u, e2, wn, v;
+    uint64_t sx, s1;
+    const uint32_t k80 = 0x80000000u;
+    uint32_t x = 0, a = rowm2 + 130u; // nothing is pending yet: a zero for the spare slot
+    e = 31u << 24;
+    asm volatile(
+        "s_mov_b64 %[sx], exec\n"
+        "1:\n\t"
+        "v_alignbit_b32 %[top], %[w0], %[w1], %[r]\n\t"                 // the next 32 bits
+        "v_lshrrev_b32_e32 %[t], 23, %[top]\n\t"
+        "v_lshl_add_u32 %[t], %[t], 2, %[lut]\n\t"
+        "ds_read_b32 %[e2], %[t]\n\t"                                   // first-level entry
+        "ds_read_b32 %[wn], %[si] offset:512\n\t"                       // the word after w1
+        ZJ_K1W_VALUE
+        "s_waitcnt lgkmcnt(1)\n\t"                                      // both reads are back (LDS answers in order)
+        "v_cmp_gt_i32_e32 vcc, 0, %[e2]\n\t"                            // bit 31: the code is longer than the first level
+        "s_cbranch_vccz 2f\n\t"
+        "s_and_saveexec_b64 %[s1], vcc\n\t"                             // the lanes with a long code look up their second entry
+        "v_bfe_u32 %[u], %[e2], 24, 3\n\t"
+        "v_sub_u32_e32 %[t], 23, %[u]\n\t"
+        "v_lshrrev_b32_e32 %[t], %[t], %[top]\n\t"
+        "v_bfe_u32 %[t], %[t], 0, %[u]\n\t"
+        "v_and_b32_e32 %[u], 0x1ff, %[e2]\n\t"
+        "v_add_lshl_u32 %[t], %[t], %[u], 2\n\t"
+        "v_add_u32_e32 %[t], %[t], %[lut]\n\t"
+        "ds_read_b32 %[e2], %[t] offset:2048\n\t"
+        "s_mov_b64 exec, %[s1]\n\t"
+        "s_waitcnt lgkmcnt(0)\n"
+        "2:\n\t"
+        ZJ_K1W_STEP
+        ZJ_K1W_VALUE                                                    // the value of every lane's last symbol
+        ZJ_K1W_OPERANDS
+        : [lut] "v"(lut), [rowm2] "v"(rowm2), [last] "v"(last), [k80] "s"(k80)
+        : "vcc", "scc", "memory");
+}
+
+// Direct form of the table (zj_build_direct_table): one lookup for every code.  t16 = the table's first code longer than
+// ZJ_L1_BITS bits, left-aligned in 16 bits (0x10000: none); with d = (next 16 bits) - t16 the entry is at index
+// (next ZJ_L1_BITS bits) + max(0, d).
+__device__ __forceinline__ void zj_k1w_symbols_direct(uint32_t &w0, uint32_t &w1, uint32_t &r, uint32_t &si, uint32_t &z, uint32_t &e,
+                                                      uint32_t lut, uint32_t t16, uint32_t rowm2, uint32_t last)
+{
+    uint32_t top, t, u, e2, wn, v;
+    uint64_t sx, s1;
+    const uint32_t k80 = 0x80000000u;
+    uint32_t x = 0, a = rowm2 + 130u; // nothing is pending yet: a zero for the spare slot
+    e = 31u << 24;
+    asm volatile(
+        "s_mov_b64 %[sx], exec\n"
+        "1:\n\t"
+        "v_alignbit_b32 %[top], %[w0], %[w1], %[r]\n\t"                 // the next 32 bits
+        "v_sub_u32_sdwa %[u], %[top], %[t16]" ZJ_K1W_SDWA("WORD_1", "DWORD")
+        "v_lshrrev_b32_e32 %[t], 23, %[top]\n\t"
+        "v_max_i32_e32 %[u], 0, %[u]\n\t"
+        "v_add_lshl_u32 %[t], %[t], %[u], 2\n\t"
+        "v_add_u32_e32 %[t], %[t], %[lut]\n\t"
+        "ds_read_b32 %[e2], %[t]\n\t"                                   // the symbol's entry
+        "ds_read_b32 %[wn], %[si] offset:512\n\t"                       // the word after w1
+        ZJ_K1W_VALUE
+        "s_waitcnt lgkmcnt(1)\n\t"                                      // both reads are back (LDS answers in order)
+        ZJ_K1W_STEP
+        ZJ_K1W_VALUE                                                    // the value of every lane's last symbol
+        ZJ_K1W_OPERANDS
+        : [lut] "v"(lut), [t16] "v"(t16), [rowm2] "v"(rowm2), [last] "v"(last), [k80] "s"(k80)
+        : "vcc", "scc", "memory");
+}
+
+// The same loop in C++, with the first-level entry supplied by `lookup(top)` (a 16-bit table entry, zj_core.h): what the
+// assembly above is checked against, and the path of table sets whose long codes need the canonical search.
+template <class LOOKUP>
+__device__ __forceinline__ void zj_k1w_symbols_ref(uint32_t &w0, uint32_t &w1, uint32_t &r, uint32_t &si, uint32_t &z, uint32_t &e,
+                                                   uint32_t rowm2, uint32_t last, LOOKUP lookup)
+{
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef __attribute__((address_space(3))) int16_t lds_i16;
+    for (;;) {
+        const uint32_t top = (uint32_t)((((uint64_t)w0 << 32) | w1) >> r);
+        const uint32_t wn = *(const lds_u32 *)(uintptr_t)(si + 512u);
+        e = zj_write_entry(lookup(top));
+        const uint32_t adv = e & 255u, len = (e >> 8) & 255u, size = 31u - (e >> 24);
+        const bool step = r < adv;
+        r = (r - adv) & 31u;
+        w0 = step ? w1 : w0;
+        w1 = step ? wn : w1;
+        si += step ? 256u : 0u;
+        z += (e >> 16) & 255u;
+        *(lds_i16 *)(uintptr_t)(rowm2 + 2u * (z < 65u ? z : 65u)) = (int16_t)zj_value_ac(top << len, size);
+        if (!(z < 64u && si <= last)) break;
+    }
+}
 
 __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[2 * ZJ_TBL_ENTRIES]; // the two AC tables
+    __shared__ __attribute__((aligned(16))) uint32_t lut[ZJ_WT_ENTRIES]; // write entries of this workgroup's AC table
     __shared__ uint32_t tile[4][64 * 33];
     __shared__ uint32_t scol[4][ZJ_K1W_SLOTS * 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t ii = P.k1w_img[blockIdx.x];
     const ZjImgDev im = P.imgs[ii]; // by value: a reference would be read again after every store
-    {
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES + 2u * ZJ_TBL_ENTRIES);
-        uint4 *d4 = reinterpret_cast<uint4 *>(lut);
-        for (uint32_t i = threadIdx.x; i < 2u * ZJ_TBL_ENTRIES * 2u / 16u; i += 256u) d4[i] = s4[i];
-    }
-    const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u + 2u;
-    __syncthreads();
-
     const uint32_t nl = im.hs * im.vs, bpm = im.bpm;
+    const ZjCanon *canon = P.canons + (size_t)im.lut_set * 4u + 2u;
+    const uint16_t *glut = P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES + 2u * ZJ_TBL_ENTRIES; // the AC tables in their 16-bit form
     const uint32_t shl = nl == 4u ? 2u : (nl == 2u ? 1u : 0u);     // log2 of the luma blocks per MCU
     const uint32_t M = im.k1w_mcus;                                // MCUs per wavefront
     const uint32_t m0 = im.row0 * im.mcux + ((blockIdx.x - im.first_k1w) * 4u + wave) * M; // first MCU of this wavefront
     const uint32_t nmcu = min(im.nblocks / bpm, (im.row0 + im.nrows) * im.mcux); // end of the rows that are wanted
-    if (m0 >= nmcu) return; // wave-uniform
-    const uint32_t rounds_l = (M << shl) / 64u, rounds = rounds_l + M * (bpm - nl) / 64u; // no chroma rounds for one component
     uint32_t *row32 = &tile[wave][lane * 33u];
     int16_t *row = reinterpret_cast<int16_t *>(row32);
     uint32_t *col = &scol[wave][lane];
+    const uint32_t colb = zj_lds_addr(col), rowm2 = zj_lds_addr(row32) - 2u, lutb = zj_lds_addr(lut);
+    const uint32_t last = colb + (ZJ_K1W_SLOTS - 3u) * 256u; // the reader needs two words behind its own
     uint32_t status = 0;
     // images without restart markers have one segment: its description is the same for every block
     const bool oneseg = im.ri_blocks == 0u;
@@ -1110,172 +1251,188 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
         pay = P.seg_payload_bits[seg];
         stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[seg].out_off);
     }
-    // What a lane needs to know about its block of a round, and the first 64 bytes of the block's bits.
-    // Both are fetched ahead of the round that uses them -- the description two rounds ahead, the bits
-    // one round ahead (their address comes out of the description) -- so that a round starts decoding
-    // at once instead of waiting for two dependent trips to memory.
-    // The loads of a description are unconditional (indices clamped to an existing block) and what they
-    // return is only looked at through have / has_next in the round that uses it: a load under a
-    // condition, or a value converted on the spot, would make the wavefront wait for memory right here.
-    struct Desc {
-        uint32_t p0, pnext, pay, kb, dcbits;
-        uint32_t dc; // the DC value's 16 bits
-        const uint32_t *stream;
-        bool valid, have, has_next; // the block exists / its position is known / so is the next block's
-    };
-    auto describe = [&](uint32_t r) -> Desc {
-        Desc d;
-        d.valid = false; d.have = false; d.has_next = false; d.p0 = 0; d.pnext = 0; d.pay = 0; d.kb = 0; d.stream = nullptr; d.dc = 0;
-        d.dcbits = 0;
-        if (r >= rounds) return d; // uniform
-        const bool luma = r < rounds_l;
-        const uint32_t sh = luma ? shl : 1u;
-        const uint32_t qi = (luma ? r : r - rounds_l) * 64u + lane;
-        const uint32_t mcu = m0 + (qi >> sh);
-        d.kb = (luma ? 0u : nl) + (qi & ((1u << sh) - 1u));
-        d.valid = mcu < nmcu;
-        const uint32_t gl = d.valid ? mcu * bpm + d.kb : 0u; // block index inside the image
-        const uint32_t g = im.first_block + gl;
-        uint32_t gs = gl, fnd = found;
-        d.pay = pay;
-        d.stream = stream;
-        if (!oneseg) { // uniform
-            const uint32_t segi = gl / im.ri_blocks;
-            const uint32_t sgi = im.first_seg + segi;
-            gs = gl - segi * im.ri_blocks;
-            fnd = min(P.seg_found[sgi], P.segs[sgi].nblocks);
-            d.pay = P.seg_payload_bits[sgi];
-            d.stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[sgi].out_off);
+    // A wavefront takes all luma blocks of its MCUs first (phase 0), then all chroma blocks (phase 1): the workgroup
+    // holds one AC table in LDS at a time -- in its direct form a table takes up to ZJ_WT_ENTRIES entries -- and
+    // changes it between the phases, which its wavefronts enter together.
+    for (uint32_t phase = 0; phase < 2u; phase++) {
+        const bool luma = phase == 0;
+        if (!luma && bpm == nl) break; // one component: no chroma blocks (uniform)
+        const uint32_t tac0 = (im.acsel >> (luma ? 0u : nl)) & 1u;          // the AC table of these blocks
+        const bool mixed = !luma && ((im.acsel >> (nl + 1u)) & 1u) != tac0; // Cb and Cr with different AC tables
+        const uint32_t t16 = P.wt_info[im.lut_set * 2u + tac0]; // ZJ_WT_TWO_LEVEL, or the parameter of the direct form
+        if (luma || tac0 != (im.acsel & 1u)) { // uniform: the chroma blocks may use the luma table
+            if (phase) __syncthreads(); // every wavefront is done with the luma table
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(P.wtabs + (size_t)(im.lut_set * 2u + tac0) * ZJ_WT_ENTRIES);
+            uint4 *d4 = reinterpret_cast<uint4 *>(lut);
+            for (uint32_t i = threadIdx.x; i < ZJ_WT_ENTRIES * 4u / 16u; i += 256u) d4[i] = s4[i];
+            __syncthreads();
         }
-        d.have = d.valid && gs < fnd;
-        d.has_next = d.have && gs + 1u < fnd;
-        const uint32_t gi = d.have ? g : im.first_block;
-        d.p0 = P.blockpos[gi];
-        d.dc = (uint16_t)P.dcabs[gi];
-        d.dcbits = P.dcbits[gi];
-        d.pnext = P.blockpos[d.has_next ? g + 1u : gi];
-        return d;
-    };
-    ZjU4 h0 = {0, 0, 0, 0}, h1 = h0, h2 = h0, h3 = h0; // bits of the current round's block
-    auto fetch_head = [&](const Desc &d, ZjU4 &c0, ZjU4 &c1, ZjU4 &c2, ZjU4 &c3) {
-        // unconditional as well: a lane without a block reads the head of the arena and ignores it
-        const ZjU4 *src = d.have ? reinterpret_cast<const ZjU4 *>(d.stream) + (d.p0 >> 7) : reinterpret_cast<const ZjU4 *>(P.ust);
-        c0 = src[0]; c1 = src[1]; c2 = src[2]; c3 = src[3];
-    };
-    auto stage = [&](const ZjU4 &c0, const ZjU4 &c1, const ZjU4 &c2, const ZjU4 &c3) {
-#define ZJ_SW(x) __builtin_bswap32(x)
-        col[0 * 64] = ZJ_SW(c0.x); col[1 * 64] = ZJ_SW(c0.y); col[2 * 64] = ZJ_SW(c0.z); col[3 * 64] = ZJ_SW(c0.w);
-        col[4 * 64] = ZJ_SW(c1.x); col[5 * 64] = ZJ_SW(c1.y); col[6 * 64] = ZJ_SW(c1.z); col[7 * 64] = ZJ_SW(c1.w);
-        col[8 * 64] = ZJ_SW(c2.x); col[9 * 64] = ZJ_SW(c2.y); col[10 * 64] = ZJ_SW(c2.z); col[11 * 64] = ZJ_SW(c2.w);
-        col[12 * 64] = ZJ_SW(c3.x); col[13 * 64] = ZJ_SW(c3.y); col[14 * 64] = ZJ_SW(c3.z); col[15 * 64] = ZJ_SW(c3.w);
-#undef ZJ_SW
-    };
-    // Order of memory operations in a round: the description of the round after next is requested at the
-    // top; the bits of the next round's block (requested a round ago) are staged into the column at the
-    // bottom, after this round's block is done with it and before the coefficient stores are issued, and
-    // the request for the bits after those follows at once.  Nothing ever waits for an operation that
-    // has not had a whole round to complete -- in particular not for the stores.
-    Desc cur = describe(0);
-    fetch_head(cur, h0, h1, h2, h3);
-    Desc nxt = describe(1);
-    stage(h0, h1, h2, h3);
-    fetch_head(nxt, h0, h1, h2, h3);
-    for (uint32_t r = 0; r < rounds; r++) {
-#pragma unroll
-        for (int i = 0; i < 33; i++) row32[i] = 0;
-        const bool luma = r < rounds_l;
-        const uint32_t sh = luma ? shl : 1u;
-        const uint32_t qbase = (luma ? r : r - rounds_l) * 64u;
-        const Desc nn = describe(r + 2u);
+        // the table sets whose long codes need the canonical search, and rounds whose lanes use two tables, take the
+        // loop in C++ with the 16-bit tables in global memory
+        const bool use_ref = (im.flags & 2u) != 0 || mixed; // uniform
+        const bool direct = t16 != ZJ_WT_TWO_LEVEL;         // uniform
+        const uint32_t sh = luma ? shl : 1u;                // log2 of this phase's blocks per MCU
+        const uint32_t rounds = m0 < nmcu ? (M << sh) / 64u : 0u; // a wavefront behind the last MCU only takes part in the barriers
+        // What a lane needs to know about its block of a round, and the first 56 bytes of the block's bits.
+        // Both are fetched ahead of the round that uses them -- the description two rounds ahead, the bits
+        // one round ahead (their address comes out of the description) -- so that a round starts decoding
+        // at once instead of waiting for two dependent trips to memory.
+        // The loads of a description are unconditional (indices clamped to an existing block) and what they
+        // return is only looked at through have / has_next in the round that uses it: a load under a
+        // condition, or a value converted on the spot, would make the wavefront wait for memory right here.
+        struct Desc {
+            uint32_t p0, pnext, pay, kb, dcbits;
+            uint32_t dc; // the DC value's 16 bits
+            const uint32_t *stream;
+            bool valid, have, has_next; // the block exists / its position is known / so is the next block's
+        };
+        auto describe = [&](uint32_t r) -> Desc {
+            Desc d;
+            d.valid = false; d.have = false; d.has_next = false; d.p0 = 0; d.pnext = 0; d.pay = 0; d.kb = 0; d.stream = nullptr; d.dc = 0;
+            d.dcbits = 0;
+            if (r >= rounds) return d; // uniform
+            const uint32_t qi = r * 64u + lane;
+            const uint32_t mcu = m0 + (qi >> sh);
+            d.kb = (luma ? 0u : nl) + (qi & ((1u << sh) - 1u));
+            d.valid = mcu < nmcu;
+            const uint32_t gl = d.valid ? mcu * bpm + d.kb : 0u; // block index inside the image
+            const uint32_t g = im.first_block + gl;
+            uint32_t gs = gl, fnd = found;
+            d.pay = pay;
+            d.stream = stream;
+            if (!oneseg) { // uniform
+                const uint32_t segi = gl / im.ri_blocks;
+                const uint32_t sgi = im.first_seg + segi;
+                gs = gl - segi * im.ri_blocks;
+                fnd = min(P.seg_found[sgi], P.segs[sgi].nblocks);
+                d.pay = P.seg_payload_bits[sgi];
+                d.stream = reinterpret_cast<const uint32_t *>(P.ust + P.segs[sgi].out_off);
+            }
+            d.have = d.valid && gs < fnd;
+            d.has_next = d.have && gs + 1u < fnd;
+            const uint32_t gi = d.have ? g : im.first_block;
+            d.p0 = P.blockpos[gi];
+            d.dc = (uint16_t)P.dcabs[gi];
+            d.dcbits = P.dcbits[gi];
+            d.pnext = P.blockpos[d.has_next ? g + 1u : gi];
+            return d;
+        };
+        // fourteen stream words from word `word` of `src` on
+        struct Head {
+            zj_u32x4_a4 a, b, c;
+            zj_u32x2_a4 d;
+        };
+        static_assert(ZJ_K1W_SLOTS == 13u || ZJ_K1W_SLOTS == 14u, "the head loads below fetch 13 or 14 words");
+        auto fetch_words = [&](const uint32_t *src, uint32_t word, Head &h) {
+            const uint32_t *q = src + word;
+            h.a = *reinterpret_cast<const zj_u32x4_a4 *>(q);
+            h.b = *reinterpret_cast<const zj_u32x4_a4 *>(q + 4);
+            h.c = *reinterpret_cast<const zj_u32x4_a4 *>(q + 8);
+            if (ZJ_K1W_SLOTS == 14u) h.d = *reinterpret_cast<const zj_u32x2_a4 *>(q + 12);
+            else { h.d.x = q[12]; h.d.y = 0; }
+        };
+        auto fetch_head = [&](const Desc &d, Head &h) {
+            // unconditional as well: a lane without a block reads the head of the arena and ignores it
+            fetch_words(d.have ? d.stream : reinterpret_cast<const uint32_t *>(P.ust), d.have ? d.p0 >> 5 : 0u, h);
+        };
+        auto stage = [&](const Head &h) {
+    #define ZJ_SW(x) __builtin_bswap32(x)
+            col[0 * 64] = ZJ_SW(h.a.x); col[1 * 64] = ZJ_SW(h.a.y); col[2 * 64] = ZJ_SW(h.a.z); col[3 * 64] = ZJ_SW(h.a.w);
+            col[4 * 64] = ZJ_SW(h.b.x); col[5 * 64] = ZJ_SW(h.b.y); col[6 * 64] = ZJ_SW(h.b.z); col[7 * 64] = ZJ_SW(h.b.w);
+            col[8 * 64] = ZJ_SW(h.c.x); col[9 * 64] = ZJ_SW(h.c.y); col[10 * 64] = ZJ_SW(h.c.z); col[11 * 64] = ZJ_SW(h.c.w);
+            col[12 * 64] = ZJ_SW(h.d.x);
+            if (ZJ_K1W_SLOTS == 14u) col[13 * 64] = ZJ_SW(h.d.y);
+    #undef ZJ_SW
+        };
+        // Order of memory operations in a round: the description of the round after next is requested at the
+        // top; the bits of the next round's block (requested a round ago) are staged into the column at the
+        // bottom, after this round's block is done with it and before the coefficient stores are issued, and
+        // the request for the bits after those follows at once.  Nothing ever waits for an operation that
+        // has not had a whole round to complete -- in particular not for the stores.
+        Head hd;
+        Desc cur = describe(0);
+        fetch_head(cur, hd);
+        Desc nxt = describe(1);
+        stage(hd);
+        fetch_head(nxt, hd);
+        for (uint32_t r = 0; r < rounds; r++) {
+    #pragma unroll
+            for (int i = 0; i < 33; i++) row32[i] = 0;
+            const uint32_t qbase = r * 64u;
+            const Desc nn = describe(r + 2u);
 
-        // ---- this round's block (src/decoder.rs:186-235; the DC value comes from the prefix scan)
-        const uint32_t dcb = cur.have ? cur.dcbits : ZJ_DC_BAD;
-        const uint32_t pnext = cur.has_next ? cur.pnext : 0xFFFFFFFFu;
-        uint32_t p = cur.p0 + dcb, z = 1, e = 0x0100u, z2 = 0;
-        bool live = cur.valid && dcb != ZJ_DC_BAD;            // still has symbols to decode
-        if (cur.valid && !live) status |= cur.have ? 1u : 4u; // no DC code / no position: bad code / truncated
-        if (live) row[0] = (int16_t)cur.dc;
-        uint32_t wa = (cur.p0 >> 7) << 2; // stream word held in slot 0 of the column
-        const uint16_t *ac = lut + ((im.acsel >> cur.kb) & 1u) * ZJ_TBL_ENTRIES;
-        const ZjCanon *cac = canon + ((im.acsel >> cur.kb) & 1u);
-        const bool use_canon = (im.flags & 2u) != 0; // wave-uniform
-        for (;;) {
-            if (live) {
-                // position the reader: the column holds the 16 words from word wa on
-                // the reader's slot as a word index into the column (an index, not a pointer: pointer arithmetic
-                // in this loop is done in 64 bits)
-                uint32_t si = ((p >> 5) - wa) * 64u;
-                uint32_t w0 = col[si], w1 = col[si + 64u], o = p & 31u;
-                constexpr uint32_t last = (ZJ_K1W_SLOTS - 3u) * 64u; // the reader needs two words behind its own
-                // one symbol per turn; the loop has a single exit so that it stays one straight run of code
-                auto turn = [&](auto with_canon) -> bool {
-                    const uint32_t top = (uint32_t)(((((uint64_t)w0 << 32) | w1) << o) >> 32);
-                    const uint32_t wn = col[si + 128u];
-                    e = zj_lookup<decltype(with_canon)::value, true>(ac, cac, top);
-                    const uint32_t len = (e >> 8) & 31u, sz = e & 15u;
-                    z2 = z + ((e >> 4) & 15u);                 // src/decoder.rs:225
-                    const bool eob = (e & 255u) == 0;          // :212 (a pattern that is no code reads as 0 too)
-                    // :228 would index out of bounds at 64 and above (slot 64 is spare).  An EOB or a ZRL
-                    // has no value bits, so what it stores is a zero into a slot that is zero anyway.
-                    row[z2 < 64u ? z2 : 64u] = (int16_t)zj_value_ac(top << len, sz);
-                    const uint32_t adv = len + sz;
-                    z = z2 + 1u;                               // :230
-                    o += adv;
-                    const bool step = o >= 32u;
-                    w0 = step ? w1 : w0;
-                    w1 = step ? wn : w1;
-                    si += step ? 64u : 0u;
-                    o &= 31u;
-                    live = !(eob || z2 >= 63u);                // :212, :232 (and the overflow case)
-                    return live && si <= last;                 // out of staged bits: wait for the others, then restage
-                };
-                if (use_canon) { while (turn(std::true_type{})) {} }
-                else { while (turn(std::false_type{})) {} }
-                // the reader's position in bits; when the block has just ended, its last symbol was not
-                // taken off the word offset (o wraps at 32), which the slot count makes up for
-                p = (wa + si / 64u) * 32u + o;
+            // ---- this round's block (src/decoder.rs:186-235; the DC value comes from the prefix scan)
+            const uint32_t dcb = cur.have ? cur.dcbits : ZJ_DC_BAD;
+            const uint32_t pnext = cur.has_next ? cur.pnext : 0xFFFFFFFFu;
+            uint32_t p = cur.p0 + dcb, z = 1, e = ZJ_WE_START; // p >= 1: a DC symbol has at least one bit
+            bool live = cur.valid && dcb != ZJ_DC_BAD;            // still has symbols to decode
+            if (cur.valid && !live) status |= cur.have ? 1u : 4u; // no DC code / no position: bad code / truncated
+            if (live) row[0] = (int16_t)cur.dc;
+            uint32_t wa = cur.p0 >> 5; // stream word held in slot 0 of the column
+            const uint32_t tac = (im.acsel >> cur.kb) & 1u;
+            for (;;) {
+                if (live) {
+                    // position the reader on bit p: the column holds the 14 words from word wa on
+                    const uint32_t pm = p - 1u;
+                    uint32_t si = colb + ((pm >> 5) - wa) * 256u;
+                    uint32_t w0 = *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)si;
+                    uint32_t w1 = *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)(si + 256u);
+                    uint32_t rr = ~pm & 31u;
+    #ifndef ZJ_K1W_NOASM
+                    if (!use_ref && direct) zj_k1w_symbols_direct(w0, w1, rr, si, z, e, lutb, t16, rowm2, last);
+                    else if (!use_ref) zj_k1w_symbols(w0, w1, rr, si, z, e, lutb, rowm2, last);
+                    else
+    #endif
+                    {
+                        const uint16_t *ac = glut + tac * ZJ_TBL_ENTRIES;
+                        const ZjCanon *cac = canon + tac;
+                        zj_k1w_symbols_ref(w0, w1, rr, si, z, e, rowm2, last, [&](uint32_t top) { return zj_lookup<true, false>(ac, cac, top); });
+                    }
+                    p = (wa + ((si - colb) >> 8)) * 32u + 32u - rr;
+                    live = z < 64u;
+                }
+                if (!__any(live)) break;
+                if (live) { // out of staged bits: restage from the word that holds bit p - 1
+                    Head h2;
+                    wa = (p - 1u) >> 5;
+                    fetch_words(cur.stream, wa, h2);
+                    stage(h2);
+                }
             }
-            if (!__any(live)) break;
-            if (live) {
-                const ZjU4 *src = reinterpret_cast<const ZjU4 *>(cur.stream) + (p >> 7);
-                const ZjU4 c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
-                stage(c0, c1, c2, c3);
-                wa = (p >> 7) << 2;
+            if (cur.valid && dcb != ZJ_DC_BAD) {
+                uint32_t st = 0;
+                if (((e >> 8) & 255u) == 0) st = 1u;                            // ZJ_ST_BAD_CODE
+                else if (((e >> 16) & 255u) < 64u && z >= 65u) st = 2u;         // ZJ_ST_COEF_OVERFLOW: a run past coefficient 63
+                if (p > cur.pay) st |= 4u;                                      // ZJ_ST_TRUNCATED
+                // a cleanly decoded block ends where the next one begins; if it does not, the position
+                // list does not describe the sequential decode
+                if (st == 0u && pnext != 0xFFFFFFFFu && pnext != p) { atomicOr(&P.flags[1], 1u); atomicAdd(&P.flags[3], 1u); }
+                status |= st;
             }
-        }
-        if (cur.valid && dcb != ZJ_DC_BAD) {
-            uint32_t st = 0;
-            if (((e >> 8) & 31u) == 0) st = 1u;                        // ZJ_ST_BAD_CODE
-            else if ((e & 255u) != 0 && z2 >= 64u) st = 2u;            // ZJ_ST_COEF_OVERFLOW
-            if (p > cur.pay) st |= 4u;                                 // ZJ_ST_TRUNCATED
-            // a cleanly decoded block ends where the next one begins; if it does not, the position
-            // list does not describe the sequential decode
-            if (st == 0u && pnext != 0xFFFFFFFFu && pnext != p) { atomicOr(&P.flags[1], 1u); atomicAdd(&P.flags[3], 1u); }
-            status |= st;
-        }
-        cur = nxt; nxt = nn;
-        // Pin the rotation here, where the loads of this round's description are long complete and no store is
-        // in flight: left to itself the compiler copies the registers at the loop's back edge, behind the
-        // stores below, and has to wait there for every outstanding memory operation, stores included.
-        asm volatile("" : "+v"(nxt.p0), "+v"(nxt.pnext), "+v"(nxt.dcbits), "+v"(nxt.dc));
-        // the column is free: the next round's bits go in, and the head registers take the bits after those
-        stage(h0, h1, h2, h3);
-        fetch_head(nxt, h0, h1, h2, h3);
-        zj_wave_lds_sync();
-        // store: piece q = (row q / 8, sixteen bytes q % 8); the row's block is recomputed from its lane
-#pragma unroll
-        for (uint32_t it = 0; it < 8u; it++) {
-            const uint32_t q = it * 64u + lane;
-            const uint32_t rl = q >> 3, part = q & 7u;
-            const uint32_t qj = qbase + rl;
-            const uint32_t mj = m0 + (qj >> sh);
-            if (mj < nmcu) {
-                const uint32_t gj = im.first_block + mj * bpm + (luma ? 0u : nl) + (qj & ((1u << sh) - 1u));
-                const uint32_t *src = &tile[wave][rl * 33u + part * 4u];
-                *reinterpret_cast<uint4 *>(P.qcoef + (size_t)gj * 64u + part * 8u) = make_uint4(src[0], src[1], src[2], src[3]);
+            cur = nxt; nxt = nn;
+            // Pin the rotation here, where the loads of this round's description are long complete and no store is
+            // in flight: left to itself the compiler copies the registers at the loop's back edge, behind the
+            // stores below, and has to wait there for every outstanding memory operation, stores included.
+            asm volatile("" : "+v"(nxt.p0), "+v"(nxt.pnext), "+v"(nxt.dcbits), "+v"(nxt.dc));
+            // the column is free: the next round's bits go in, and the head registers take the bits after those
+            stage(hd);
+            fetch_head(nxt, hd);
+            zj_wave_lds_sync();
+            // store: piece q = (row q / 8, sixteen bytes q % 8); the row's block is recomputed from its lane
+    #pragma unroll
+            for (uint32_t it = 0; it < 8u; it++) {
+                const uint32_t q = it * 64u + lane;
+                const uint32_t rl = q >> 3, part = q & 7u;
+                const uint32_t qj = qbase + rl;
+                const uint32_t mj = m0 + (qj >> sh);
+                if (mj < nmcu) {
+                    const uint32_t gj = im.first_block + mj * bpm + (luma ? 0u : nl) + (qj & ((1u << sh) - 1u));
+                    const uint32_t *src = &tile[wave][rl * 33u + part * 4u];
+                    *reinterpret_cast<uint4 *>(P.qcoef + (size_t)gj * 64u + part * 8u) = make_uint4(src[0], src[1], src[2], src[3]);
+                }
             }
+            zj_wave_lds_sync();
         }
-        zj_wave_lds_sync();
     }
     if (status) atomicOr(&P.status[ii], status);
 }
@@ -1600,8 +1757,11 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
 
 // One instantiation per sampling layout, so that each gets its own register allocation.  `first`
 // is where this layout's workgroups begin in P.strip_img.
+#ifndef ZJ_K2_WAVES
+#define ZJ_K2_WAVES 1 // minimum wavefronts per SIMD the register allocation must leave room for
+#endif
 template <int HS, int VS>
-__global__ __launch_bounds__(256) void zj_k2_idct_rgb(ZjParams P, uint32_t first)
+__global__ __launch_bounds__(256, ZJ_K2_WAVES) void zj_k2_idct_rgb(ZjParams P, uint32_t first)
 {
     __shared__ __attribute__((aligned(16))) float blk[4u * zj_k2_wave_mcus(HS, VS) * (HS * VS + 2) * ZJ_K2_BSTRIDE];
     __shared__ __attribute__((aligned(16))) uint16_t qlds[3 * 64];

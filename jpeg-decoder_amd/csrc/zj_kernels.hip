@@ -1418,17 +1418,20 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
             stage(hd);
             fetch_head(nxt, hd);
             zj_wave_lds_sync();
-            // store: piece q = (row q / 8, sixteen bytes q % 8); the row's block is recomputed from its lane
-    #pragma unroll
-            for (uint32_t it = 0; it < 8u; it++) {
-                const uint32_t q = it * 64u + lane;
-                const uint32_t rl = q >> 3, part = q & 7u;
-                const uint32_t qj = qbase + rl;
-                const uint32_t mj = m0 + (qj >> sh);
-                if (mj < nmcu) {
-                    const uint32_t gj = im.first_block + mj * bpm + (luma ? 0u : nl) + (qj & ((1u << sh) - 1u));
-                    const uint32_t *src = &tile[wave][rl * 33u + part * 4u];
-                    *reinterpret_cast<uint4 *>(P.qcoef + (size_t)gj * 64u + part * 8u) = make_uint4(src[0], src[1], src[2], src[3]);
+            // store: piece q = it * 64 + lane is sixteen bytes q % 8 of row q / 8.  Eight rows further on the block lies
+            // 8 >> sh MCUs further on, so the eight pieces of a lane are a fixed distance apart.
+            {
+                const uint32_t rl0 = lane >> 3, part = lane & 7u;
+                const uint32_t qj0 = qbase + rl0;
+                const uint32_t mj0 = m0 + (qj0 >> sh), mstep = 8u >> sh;
+                const uint32_t left = mj0 < nmcu ? nmcu - mj0 : 0u; // MCUs from this lane's first row to the end
+                const uint32_t gj0 = im.first_block + mj0 * bpm + (luma ? 0u : nl) + (qj0 & ((1u << sh) - 1u));
+                int16_t *dst = P.qcoef + (size_t)gj0 * 64u + part * 8u;
+                const size_t dstep = (size_t)mstep * bpm * 64u;
+                const uint32_t *src = &tile[wave][rl0 * 33u + part * 4u];
+#pragma unroll
+                for (uint32_t it = 0; it < 8u; it++) {
+                    if (it * mstep < left) *reinterpret_cast<uint4 *>(dst + it * dstep) = make_uint4(src[it * 264u], src[it * 264u + 1u], src[it * 264u + 2u], src[it * 264u + 3u]);
                 }
             }
             zj_wave_lds_sync();

@@ -197,23 +197,41 @@ def profile_kernels(batches, outs_of, nprof=3):
     return kt
 
 
+def kernels_sha256():
+    """Hash of the kernel sources of this tree (the same files tools/pmc_traffic.py hashes when it records counters)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("zj_kernels.hip", "zj_core.h", "zj_dev.h"):
+        h.update(open(os.path.join(ROOT, "jpeg-decoder_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def roofline_fields(kt, S, Cb, P, traffic_key=None):
+    """Roofline object of the dominant kernel.  `achieved` is measured in this run (HIP events).  `traffic` is NOT: it
+    is the PMC-derived HBM bytes per launch from the committed table profiles/traffic.json, attached only when that
+    table was taken on exactly these kernel sources (hash) and holds this workload; `traffic_source` says so."""
     alg = {"k0_unstuff": S, "k1a_sync": S, "k1b_fix": 0, "k1s_scan": 0, "k1p_positions": S, "k1d_dcscan": 0,
            "k1w_write": S + Cb, "k2_idct_rgb": Cb + P}
     dom = max((k for k in alg if k in kt), key=lambda k: kt[k])
     achieved = alg[dom] / (kt[dom] * 1e-3) / 1e9
-    traffic = None
+    traffic, source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if traffic_key and os.path.exists(tpath):
-        try:  # PMC-derived HBM bytes per launch of the dominant kernel, valid for the profiled workload only
+        try:
             t = json.load(open(tpath))
-            if t.get("workload") == traffic_key or (traffic_key == "c3:4096" and t.get("images") == 4096):
-                traffic = t["kernels"].get(dom)
-        except Exception:
-            traffic = None
+            if t.get("kernels_sha256") != kernels_sha256():
+                source = "profiles/traffic.json was taken on other kernel sources than this tree's: not attached"
+            elif traffic_key not in t.get("workloads", {}):
+                source = f"profiles/traffic.json holds no counters for workload {traffic_key}"
+            else:
+                traffic = t["workloads"][traffic_key].get(dom)
+                source = (f"profiles/traffic.json (committed; rocprofv3 PMC run of commit {t.get('commit')}, kernel sources "
+                          f"sha256 {t['kernels_sha256'][:12]} = this tree's), workload {traffic_key}; not measured in this run")
+        except Exception as e:
+            traffic, source = None, f"profiles/traffic.json unreadable: {e}"
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom],
-            "kernel_ms": round(kt[dom], 4)}
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
+            "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": round(kt[dom], 4)}
 
 
 def verify_against_oracle(files, fetch, threads):
@@ -464,7 +482,7 @@ def run_c2(a, D):
             "vs_baseline": None, "dtype": "u8/i16 entropy decode, f32 IDCT+colour", "data": "fixture",
             "config": {"workload": "c2: single-image latency, tests/golden/large.jpg (7680x4320 4:4:4, one stream without restart markers); "
                                    "porsche.jpg beside it", "timing": "device-resident", "sharding": "replicas only"},
-            "roofline": roofline_fields(kt, bc["scan"], bc["coef"], bc["rgb"]), "images": res}
+            "roofline": roofline_fields(kt, bc["scan"], bc["coef"], bc["rgb"], "c2"), "images": res}
 
 
 # ------------------------------------------------------------------------------------------ c4
@@ -561,7 +579,7 @@ def run_c4(a, D):
                        "images_per_gpu": len(my_keys), "sub_batches": len(groups), "sub_batch_images": sub, "pixel_pass_on_its_own_stream": overlap, "timing": "device-resident",
                        "sharding": "by image, longest-processing-time-first on scan bytes, no collective",
                        "workspace_bytes": {"scratch_shared": max(e[1] for e in est), "plan_per_sub_batch": max(e[0] for e in est)}},
-            "roofline": roofline_fields(kt, S, Cb, P),
+            "roofline": roofline_fields(kt, S, Cb, P, f"c4:{per_gpu}/{sub}" if D.world == 1 else None),
             "roofline_end_to_end": {"achieved": round(e2e, 1), "unit": "GB/s", "frac": round(e2e / HBM_PEAK_GBS, 4),
                                     "algorithmic_bytes_per_step_all_ranks": bytes_all, "device_ms_per_step": round(dev_ms / a.steps, 3)},
             "step_device_ms": dict(STEP_MS), "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
@@ -671,7 +689,7 @@ def run_c5(a, D, restart_free=False):
                                     f"one band of MCU rows per rank, bands gathered on rank 0"),
                        "bands_mcu_rows": bands, "timing": "device-resident, gather included",
                        "collective": "none" if D.world == 1 else f"point-to-point gather to rank 0 ({D.backend})"},
-            "roofline": roofline_fields(kt, S, Cb, P),
+            "roofline": roofline_fields(kt, S, Cb, P, ("c6" if restart_free else "c5") if D.world == 1 else None),
             "roofline_end_to_end": {"achieved": round(e2e_band, 1), "unit": "GB/s", "frac": round(e2e_band / HBM_PEAK_GBS, 4),
                                     "algorithmic_bytes_per_step_rank0_band": S + 2 * Cb + P, "device_ms_per_step": round(dev_ms / a.steps, 3),
                                     "note": "rank 0's band and its stream time, which includes waiting for the gather"},

@@ -191,8 +191,9 @@ int zj_batch_memory(zj_batch *b, size_t *plan_bytes, size_t *scratch_bytes);
  * stream; allocates nothing. */
 int zj_batch_decode(zj_batch *b, uint8_t *const *rgb, const size_t *stride);
 
-/* The two halves of zj_batch_decode on their own: the entropy passes (src/decoder.rs:337-404, up to the
- * coefficients) on the context's stream, and IDCT + colour conversion (src/decoder.rs:408-561) on `stream`
+/* The two halves of zj_batch_decode on their own: the entropy passes (the SOS loop, src/decoder.rs:366-390, up
+ * to the coefficients) on the context's stream, and IDCT + colour conversion (`to_rgb`, src/decoder.rs:282-320,
+ * called at :644-646) on `stream`
  * -- NULL for the context's, or another stream of the caller's on the same device, which is made to wait
  * for the entropy passes.  The entropy passes keep the arithmetic units busy and the pixel pass the memory
  * system, so a caller with several batches gains by giving the pixel passes a stream of their own: the
@@ -244,8 +245,10 @@ int zj_batch_bytes(zj_batch *b, uint64_t *scan_bytes, uint64_t *coef_bytes, uint
  * plan + decode + finish + copy-out + destroy.  outs[i].mem selects host or device outputs. */
 int zj_decode_batch(zj_ctx *ctx, const zj_image *imgs, size_t n, const zj_output *outs, uint32_t *status);
 
-/* zj_decode_batch for callers that cannot allocate device memory -- code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same work as
+/* zj_decode_batch for callers that cannot allocate device memory -- tight serving loops, code that runs between
+ * the captures of HIP graphs, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The call
+ * is synchronous (it waits for the stream and copies the status words back), so it cannot itself be captured into
+ * a graph.  Same work as
  * zj_decode_batch with ZJ_MEM_DEVICE pixel outputs (rgb[i] device pointers, NULL = skip the pixels of
  * image i; stride[i] in bytes, NULL or 0 = 3 * width), but every device buffer the decode needs -- uploaded
  * scans, tables, unstuffed streams, bitmaps, window records, block positions, quantised coefficients --

@@ -1532,6 +1532,32 @@ __device__ __forceinline__ void zj_pack24_u8(const float (&v)[24], uint32_t *w)
     w[0] = w0; w[1] = w1; w[2] = w2; w[3] = w3; w[4] = w4; w[5] = w5;
 }
 
+// The same for twelve values (three words): half the live registers around the conversions, one more pair of mode
+// switches per block row.
+__device__ __forceinline__ void zj_pack12_u8(const float (&v)[12], uint32_t *w)
+{
+    uint32_t w0, w1, w2;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\t"
+                 "s_nop 1\n\t"
+                 "v_cvt_pk_u8_f32 %0, %3, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %7, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %2, %11, 0, 0\n\t"
+                 "v_cvt_pk_u8_f32 %0, %4, 1, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %8, 1, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %12, 1, %2\n\t"
+                 "v_cvt_pk_u8_f32 %0, %5, 2, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %9, 2, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %13, 2, %2\n\t"
+                 "v_cvt_pk_u8_f32 %0, %6, 3, %0\n\t"
+                 "v_cvt_pk_u8_f32 %1, %10, 3, %1\n\t"
+                 "v_cvt_pk_u8_f32 %2, %14, 3, %2\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0"
+                 : "=&v"(w0), "=&v"(w1), "=&v"(w2)
+                 : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
+                   "v"(v[10]), "v"(v[11]));
+    w[0] = w0; w[1] = w1; w[2] = w2;
+}
+
 // Byte offset (4 * natural index) of the zig-zag positions 8*part .. 8*part+7, one byte each: the
 // inverse of the table at src/decoder.rs:114-124, i.e. the zig-zag scan order of T.81 Figure A.6.
 #define ZJ_NAT8(a, b, c, d, e, f, g, h)                                                                            \
@@ -1577,6 +1603,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
     constexpr int NIT = (NTASK + 63) / 64;
     constexpr int NW = MW * 3 / 4;        // packed RGB words per lane and task
     constexpr int PIECES = ROWB / 16;
+    constexpr bool CHROMA_FIRST = HS * VS > 1; // subsampled chroma: its rows are transformed once, ahead of the pixel rows
     // the few descriptor fields of the loop, read once (through the reference they would be read again,
     // and waited for, after every store)
     const uint32_t im_first_block = im.first_block, im_h = im.h, im_mcux = im.mcux, im_strips_x = im.strips_x, im_w = im.w, im_row0 = im.row0;
@@ -1661,8 +1688,86 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
         }
         zj_wave_lds_sync();
         // phase 3: 1-D IDCT over the rows (src/dct.rs:113-120), +128, replicate chroma, colour
-        // (src/decoder.rs:306-312).  One lane per (pixel row r, MCU m) of the tile.
+        // (src/decoder.rs:306-312).
         uint32_t px[NIT][NW];
+        if constexpr (CHROMA_FIRST) {
+            // Subsampled chroma: a chroma row serves several pixel rows (and both halves of a wide MCU), so the
+            // rows of the chroma blocks are transformed once, in place, one lane per (chroma block, row) -- the
+            // same chain on the same operands as every pixel-row task would otherwise repeat for itself.
+#pragma unroll
+            for (int it = 0; it < (2 * TW * 8 + 63) / 64; it++) {
+                const uint32_t q = lane + it * 64u;
+                const uint32_t cblk = q >> 3, row = q & 7u;
+                float *rp = blk + ((cblk >> 1) * BPM + HS * VS + (cblk & 1u)) * ZJ_K2_BSTRIDE + row * 8u;
+                if (q < (uint32_t)(2 * TW * 8)) {
+                    float in[8], out[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) in[k] = rp[k];
+                    zj_idct_1d(in, out);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) rp[k] = out[k];
+                }
+            }
+            zj_wave_lds_sync();
+            // One lane per (pixel row r, MCU m) of the tile, one block column u of the MCU at a time (the same for
+            // every lane, so that the chroma columns of the block are the same registers in every lane).
+            static_assert(NTASK == 64 && NIT == 1, "one (pixel row, MCU) task per lane");
+            const uint32_t m = lane / MH, r = lane % MH;
+            constexpr int NCS = 8 / HS; // chroma samples under the eight pixels of a block row
+#pragma unroll
+            for (int u = 0; u < HS; u++) {
+                float cb[NCS], cr[NCS], in[8], yv[8];
+                const float *cbp = blk + (m * BPM + HS * VS) * ZJ_K2_BSTRIDE + (r / VS) * 8u + u * NCS;
+                const float *yp = blk + (m * BPM + (r / 8u) * HS + u) * ZJ_K2_BSTRIDE + (r % 8u) * 8u;
+#pragma unroll
+                for (int k = 0; k < NCS; k++) { cb[k] = cbp[k]; cr[k] = cbp[ZJ_K2_BSTRIDE + k]; }
+#pragma unroll
+                for (int k = 0; k < 8; k++) in[k] = yp[k];
+                zj_idct_1d(in, yv);
+                // per chroma sample: the products of src/decoder.rs:271-273, computed once and shared by the
+                // pixels that replicate the sample.  (x + 128) - 128 is kept as two operations.
+                float pr[NCS], pg[NCS], pb[NCS];
+#pragma unroll
+                for (int c = 0; c < NCS; c++) {
+                    const float cbd = (cb[c] + 128.0f) - 128.0f;
+                    const float crd = (cr[c] + 128.0f) - 128.0f;
+                    pr[c] = 1.402f * crd;
+                    pg[c] = -0.71414f * crd + -0.34414f * cbd;
+                    pb[c] = 1.772f * cbd;
+                }
+#ifdef ZJ_K2_PACK12
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    float rgbv[12]; // four pixels of this block row, r g b each
+#pragma unroll
+                    for (int x = 4 * h; x < 4 * h + 4; x += 2) {
+                        const int cx0 = x / HS, cx1 = (x + 1) / HS, o = 3 * (x - 4 * h);
+                        const zj_f32x2 y2 = zj_f32x2{yv[x], yv[x + 1]} + zj_f32x2{128.0f, 128.0f};
+                        const zj_f32x2 r2 = zj_f32x2{pr[cx0], pr[cx1]} + y2;
+                        const zj_f32x2 g2 = zj_f32x2{pg[cx0], pg[cx1]} + y2;
+                        const zj_f32x2 b2 = zj_f32x2{pb[cx0], pb[cx1]} + y2;
+                        rgbv[o + 0] = r2.x; rgbv[o + 1] = g2.x; rgbv[o + 2] = b2.x;
+                        rgbv[o + 3] = r2.y; rgbv[o + 4] = g2.y; rgbv[o + 5] = b2.y;
+                    }
+                    zj_pack12_u8(rgbv, &px[0][u * 6 + h * 3]); // bytes u*24 + h*12 .. +11 of the lane's run
+                }
+#else
+                float rgbv[24]; // the eight pixels of this block row, r g b each
+#pragma unroll
+                for (int x = 0; x < 8; x += 2) {
+                    const int cx0 = x / HS, cx1 = (x + 1) / HS;
+                    const zj_f32x2 y2 = zj_f32x2{yv[x], yv[x + 1]} + zj_f32x2{128.0f, 128.0f};
+                    const zj_f32x2 r2 = zj_f32x2{pr[cx0], pr[cx1]} + y2;
+                    const zj_f32x2 g2 = zj_f32x2{pg[cx0], pg[cx1]} + y2;
+                    const zj_f32x2 b2 = zj_f32x2{pb[cx0], pb[cx1]} + y2;
+                    rgbv[3 * x + 0] = r2.x; rgbv[3 * x + 1] = g2.x; rgbv[3 * x + 2] = b2.x;
+                    rgbv[3 * x + 3] = r2.y; rgbv[3 * x + 4] = g2.y; rgbv[3 * x + 5] = b2.y;
+                }
+                zj_pack24_u8(rgbv, &px[0][u * 6]); // bytes u*24 .. u*24+23 of the lane's run
+#endif
+            }
+        } else {
+            // One lane per (pixel row r, MCU m) of the tile.
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             const uint32_t q = lane + it * 64u;
@@ -1710,6 +1815,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
                     zj_pack24_u8(rgbv, &px[it][u * 6]); // bytes u*24 .. u*24+23 of the lane's run
                 }
             }
+        }
         }
         zj_wave_lds_sync();
         // phase 4: RGB rows of the tile into LDS (reusing the block area), then a linear copy per pixel

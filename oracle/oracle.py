@@ -26,6 +26,7 @@ class Info(C.Structure):
         ("nblocks", C.c_int64),
         ("scan_off", C.c_int64), ("scan_len", C.c_int64), ("scan_consumed", C.c_int64),
         ("nsymbols", C.c_uint64), ("nshort", C.c_uint64), ("nff00", C.c_uint64),
+        ("err_block", C.c_int64),
     ]
 
 
@@ -105,7 +106,9 @@ def decode(data: bytes, want_rgb=True, want_coef=True) -> Decoded:
                      _p(d, C.c_int16) if want_coef else None,
                      _p(rgb, C.c_uint8) if want_rgb else None, C.byref(info2))
     if info2.status != OK:
-        return Decoded(info2, None, None, None)
+        # an entropy error (HUFF / COEF / TRUNC, where the reference panics): the blocks before info.err_block are complete
+        keep = want_coef and info2.status in (E_HUFF, E_COEF, E_TRUNC) and info2.err_block >= 0
+        return Decoded(info2, q[: info2.err_block] if keep else None, d[: info2.err_block] if keep else None, None)
     return Decoded(info2, q, d, rgb)
 
 

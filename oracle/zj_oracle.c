@@ -327,6 +327,9 @@ typedef struct {
     uint64_t nsymbols;          /* Huffman symbols decoded (DC + AC)                                      */
     uint64_t nshort;            /* of those, taken on the short path of src/ec.rs:22-27                    */
     uint64_t nff00;             /* FF 00 pairs inside the scan                                             */
+    int64_t err_block;          /* scan-order index of the block whose decode failed (status HUFF/COEF/TRUNC), -1: none.
+                                 * The reference panics inside that block (src/decoder.rs:194-228, src/ec.rs:27,47);
+                                 * every block before it is complete in qcoef / dqcoef.                    */
 } zjo_info;
 
 /* Marker walk: src/decoder.rs:347-642.  All APPn / COM are skipped by length (the reference
@@ -482,7 +485,7 @@ static int decode_segment(const frame_t *f, const uint8_t *seg, size_t seglen, i
             int64_t g = m * bpm + k;
             decode_dct_matrix(&f->ht[f->ta[c]][0], &f->ht[f->td[c]][1], f->qt[f->tq[c]], &b, &dc_pred[c],
                               qcoef + g * 64, dqcoef + g * 64, &info->nsymbols, &info->nshort);
-            if (b.err) return b.err;
+            if (b.err) { info->err_block = g; return b.err; }
         }
     }
     info->scan_consumed += (int64_t)r.pos;
@@ -559,6 +562,7 @@ int zjo_probe(const uint8_t *file, size_t len, zjo_info *info)
     info->mcux = mcux; info->mcuy = mcuy; info->blocks_per_mcu = bpm;
     info->restart_interval = f.restart_interval;
     info->nblocks = (int64_t)mcux * mcuy * bpm;
+    info->err_block = -1;
     info->scan_off = (int64_t)f.scan_off; info->scan_len = (int64_t)f.scan_len;
     return ZJO_OK;
 }

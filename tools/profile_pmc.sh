@@ -24,4 +24,5 @@ pass sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS 
 pass fetch FETCH_SIZE GRBM_GUI_ACTIVE || exit 1
 pass write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum || exit 1
 python3 "$ROOT/tools/pmc_summary.py" "$OUT" > "$OUT/summary.json" && echo "summary written: $OUT/summary.json"
-python3 "$ROOT/tools/pmc_traffic.py" "$OUT/summary.json" "$IMAGES" > "$OUT/traffic.json" && echo "traffic written: $OUT/traffic.json"
+# TRAFFIC_KEY names the workload in the traffic table (bench.py looks its own workload up under the same key)
+python3 "$ROOT/tools/pmc_traffic.py" "$OUT/summary.json" "${TRAFFIC_KEY:-c3:$IMAGES}" "$ROOT/gpurun_out/traffic.json"

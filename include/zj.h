@@ -32,6 +32,7 @@ extern "C" {
 #define ZJ_E_DEVICE (-4)      /* HIP runtime error or no usable GPU; see zj_last_error              */
 #define ZJ_E_NOMEM (-5)
 #define ZJ_E_IO (-6)          /* counterpart of DecodeError::Io (src/error.rs:4-6)                  */
+#define ZJ_E_CHAIN (-7)       /* a stream split over several GPUs: the parts' walks do not join up; decode it whole */
 
 /* ---- per-image status word (bit set; 0 = decoded cleanly).  Each bit replaces one of the
  *      reference's panics on malformed entropy data. ---- */
@@ -161,6 +162,41 @@ void zj_batch_destroy(zj_batch *b);
  * restart-marked image.  Coefficients outside the window are not produced (zj_batch_export_coef returns the
  * arena as is there). */
 zj_batch *zj_batch_create_rows(zj_ctx *ctx, const zj_image *imgs, size_t n, uint32_t flags, const uint32_t *row0, const uint32_t *nrows);
+
+/* ---- one image without restart markers over several GPUs, entropy front included ----
+ * The reference decodes such a stream as one serial chain (src/decoder.rs:376-389: one BitReader, predictors carried
+ * from MCU to MCU).  Here part `rank` of `nranks` takes the bytes from `lead_bytes` in front of its boundary (rank *
+ * scan_len / nranks, moved off FF 00 pairs) to a little behind the next boundary, walks them from a guessed state as
+ * the subsequences of one GPU do, and owns the MCUs that begin between the two boundaries.  What it cannot know alone
+ * comes from one all-gather of the parts' reports (struct zj_range_report, 32 bytes each), which the caller performs:
+ *   zj_batch_create_range   plan; unstuffing, walks, block positions and DC differences will cover this part only
+ *   zj_batch_range_front    run them; fills this part's report                                   (synchronous)
+ *   -- all-gather of the reports, by the caller (RCCL / gloo / MPI ...) --
+ *   zj_batch_range_resolve  every part checks the whole chain the same way: part r's walk is the true one if part
+ *                           r-1's is and both find the same block, at the same place in its MCU, first behind their
+ *                           boundary.  Gives this part the raster index of its first MCU, its MCU count, the MCU rows
+ *                           its pixels touch, and (internally) its DC predictors = the sums of the parts before it.
+ *                           ZJ_E_CHAIN: some part had not synchronised inside its lead-in; every part gets the same
+ *                           answer, and the caller falls back to zj_batch_create_rows (front repeated on every GPU).
+ *   zj_batch_range_decode   coefficients of the MCUs owned, then IDCT + colour of MCU rows [row0, row0 + nrows) into
+ *                           `rgb` (which begins at MCU row row0).  Pixels of MCUs of those rows that other parts own
+ *                           are not meaningful: the first and the last row are shared with the neighbours, who write
+ *                           the rest of them.  Asynchronous; zj_batch_finish as usual (ZJ_E_CHAIN there too if a
+ *                           block did not end where the next begins).  May be called again (same result). */
+typedef struct zj_range_report {
+    int32_t start_delta;  /* bits from this part's boundary to the first block that begins at or behind it */
+    uint32_t start_k;     /* that block's place in its MCU according to this part's own walk */
+    int32_t end_delta;    /* the same at the next part's boundary (0 for the last part) */
+    uint32_t end_k;
+    uint32_t mcus;        /* MCUs that begin between the two boundaries */
+    int16_t dc_sum[3];    /* their DC differences summed per component (wrapping i16, src/decoder.rs:199) */
+    uint16_t reserved;
+    uint32_t reserved2;
+} zj_range_report;
+zj_batch *zj_batch_create_range(zj_ctx *ctx, const zj_image *img, uint32_t rank, uint32_t nranks, uint32_t lead_bytes, uint32_t flags);
+int zj_batch_range_front(zj_batch *b, zj_range_report *report);
+int zj_batch_range_resolve(zj_batch *b, const zj_range_report *all, uint32_t nranks, uint32_t *mcu_first, uint32_t *mcu_count, uint32_t *row0, uint32_t *nrows);
+int zj_batch_range_decode(zj_batch *b, uint8_t *rgb, size_t stride);
 
 /* ---- workspaces: device memory shared by batches that are decoded one after the other ----
  * A batch made by zj_batch_create owns every byte it uses, the coefficient arena (128 bytes per block)

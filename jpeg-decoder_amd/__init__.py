@@ -6,5 +6,5 @@ decoder    Decoder / ParsedImage / Batch: the host-side mirror of the reference'
 shard      batch partitioning over GPUs and band splitting of restart-marked images
 synth      synthetic JPEG generator for benchmarks and tests
 """
-from .decoder import (Batch, Context, DecodeError, Decoder, OutputTables, ParsedImage, Workspace,  # noqa: F401
-                      decode_images, decode_noalloc)
+from .decoder import (Batch, ChainError, Context, DecodeError, Decoder, OutputTables, ParsedImage, RangeBatch,  # noqa: F401
+                      Workspace, decode_images, decode_noalloc)

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libzj.so")
 
-ZJ_OK, ZJ_E_INVALID, ZJ_E_FORMAT, ZJ_E_UNSUPPORTED, ZJ_E_DEVICE, ZJ_E_NOMEM, ZJ_E_IO = 0, -1, -2, -3, -4, -5, -6
+ZJ_OK, ZJ_E_INVALID, ZJ_E_FORMAT, ZJ_E_UNSUPPORTED, ZJ_E_DEVICE, ZJ_E_NOMEM, ZJ_E_IO, ZJ_E_CHAIN = 0, -1, -2, -3, -4, -5, -6, -7
 ZJ_ST_BAD_CODE, ZJ_ST_COEF_OVERFLOW, ZJ_ST_TRUNCATED, ZJ_ST_UNSUPPORTED = 1, 2, 4, 8
 ZJ_MEM_HOST, ZJ_MEM_DEVICE = 0, 1
 ZJ_FLAG_NO_SECOND_LEVEL = 0x1000000
@@ -44,6 +44,11 @@ class zj_parsed(C.Structure):
     ]
 
 
+class zj_range_report(C.Structure):
+    _fields_ = [("start_delta", C.c_int32), ("start_k", C.c_uint32), ("end_delta", C.c_int32), ("end_k", C.c_uint32),
+                ("mcus", C.c_uint32), ("dc_sum", C.c_int16 * 3), ("reserved", C.c_uint16), ("reserved2", C.c_uint32)]
+
+
 class zj_output(C.Structure):
     _fields_ = [("rgb", C.c_void_p), ("rgb_stride", C.c_size_t), ("qcoef", C.c_void_p), ("dqcoef", C.c_void_p),
                 ("mem", C.c_int)]
@@ -62,6 +67,7 @@ _EXPORTS = [
     "zj_batch_counters", "zj_batch_create_rows",
     "zj_decode_batch_noalloc",
     "zj_batch_decode_entropy", "zj_batch_decode_pixels",
+    "zj_batch_create_range", "zj_batch_range_front", "zj_batch_range_resolve", "zj_batch_range_decode",
 ]
 
 
@@ -113,6 +119,10 @@ def lib():
     L.zj_decode_batch_noalloc.argtypes = [vp, C.POINTER(zj_image), sz, C.POINTER(vp), C.POINTER(sz), u32p]; L.zj_decode_batch_noalloc.restype = C.c_int
     L.zj_batch_decode_entropy.argtypes = [vp]; L.zj_batch_decode_entropy.restype = C.c_int
     L.zj_batch_decode_pixels.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), vp]; L.zj_batch_decode_pixels.restype = C.c_int
+    L.zj_batch_create_range.argtypes = [vp, C.POINTER(zj_image), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]; L.zj_batch_create_range.restype = vp
+    L.zj_batch_range_front.argtypes = [vp, C.POINTER(zj_range_report)]; L.zj_batch_range_front.restype = C.c_int
+    L.zj_batch_range_resolve.argtypes = [vp, C.POINTER(zj_range_report), C.c_uint32, u32p, u32p, u32p, u32p]; L.zj_batch_range_resolve.restype = C.c_int
+    L.zj_batch_range_decode.argtypes = [vp, vp, sz]; L.zj_batch_range_decode.restype = C.c_int
     _lib = L
     return L
 

@@ -63,6 +63,7 @@ struct zj_batch {
     std::vector<ZjImgDev> imgs;
     std::vector<ZjSegDev> segs;
     std::vector<uint32_t> unsupported; // per image: 1 = rejected at plan time
+    std::vector<uint64_t> scan_at;     // per image: where its scan begins in the raw arena
     ZjParams P;
     ZjLaunch L;
     std::vector<void *> allocs;
@@ -92,6 +93,20 @@ struct zj_batch {
     bool split_ev_valid, pixels_pending; // pixels_pending: pixels_done was recorded on a stream other than the context's
     uint32_t slow_path_calls; // zj_batch_finish calls that had to run the exhaustive fix-up loop
     uint64_t scan_bytes, coef_bytes, rgb_bytes, pixels;
+    // a part of a stream that is split over several GPUs (zj_batch_create_range), else range.on == false
+    struct {
+        bool on;
+        uint32_t rank, nranks;
+        uint64_t x_bits, y_bits;  // where this part's ownership begins and ends, in bits of its own unstuffed stream
+        bool last;                // the part that ends with the stream
+        int stage;                // 0 planned, 1 front done (report filled), 2 resolved
+        zj_range_report rep;
+        uint32_t m_first_local;   // position-list MCU of the first MCU owned
+        uint32_t g_first, g_end;  // position-list block range of the MCUs owned
+        uint32_t before[3];       // DC prefix per component in front of the first MCU owned (in this part's own scan)
+        uint32_t off[3];          // what turns that scan's values into predicted DC values
+        uint32_t per_wg, cls, strips_x; // launch geometry to redo once the MCUs owned are known
+    } range;
     bool profiling;
     hipEvent_t ev[ZJ_NUM_KERNELS + 1];
     bool ev_valid;
@@ -354,7 +369,8 @@ enum { ZJ_ALLOC_OWN = 0, ZJ_ALLOC_WORKSPACE, ZJ_ALLOC_NONE };
 // The planner behind zj_batch_create, zj_batch_create_in and zj_decode_batch_noalloc.
 // ZJ_ALLOC_NONE: plan and scratch memory both come out of the range [fixed_base, fixed_base + fixed_cap).
 static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n, uint32_t flags, int mode, zj_workspace *ws, uint32_t slot,
-                                   uint8_t *fixed_base, size_t fixed_cap, const uint32_t *win_row0 = nullptr, const uint32_t *win_nrows = nullptr)
+                                   uint8_t *fixed_base, size_t fixed_cap, const uint32_t *win_row0 = nullptr, const uint32_t *win_nrows = nullptr,
+                                   const uint64_t *seg_range = nullptr)
 {
     if (!ctx) return nullptr;
     ctx->err_code = ZJ_E_INVALID;
@@ -369,6 +385,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     b->slow_path_calls = 0;
     b->entropy_launched = false; b->split_ev_valid = false; b->pixels_pending = false;
     b->scan_bytes = b->coef_bytes = b->rgb_bytes = b->pixels = 0;
+    memset(&b->range, 0, sizeof b->range);
     b->ws = nullptr;
     b->up = ctx->stream;
     b->plan_pooled = b->scratch_pooled = false;
@@ -431,6 +448,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
         raw_off[i] = raw_total;
         raw_total += align_up(images[i].scan_len, 16) + 16;
     }
+    b->scan_at.assign(raw_off.begin(), raw_off.end());
     uint8_t *raw = dev_alloc<uint8_t>(b, raw_total + 1040, false);
     if (!raw) { zj_batch_destroy(b); return nullptr; }
     {
@@ -499,6 +517,9 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
             d.nrows = win_nrows[i];
         }
         const uint64_t wmcu = (uint64_t)d.mcux * d.nrows; // MCUs of those rows
+        d.mcu_lo = d.row0 * d.mcux;
+        d.mcu_hi = (uint32_t)std::min<uint64_t>(nmcu, (uint64_t)(d.row0 + d.nrows) * d.mcux);
+        d.mcu_shift = 0;
         for (uint32_t k = 0; k < d.bpm; k++) {
             const uint32_t c = k < d.hs * d.vs ? 0u : (k == d.hs * d.vs ? 1u : 2u);
             d.compsel |= c << (2 * k);
@@ -586,6 +607,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
                 beg = offs[(size_t)k];
                 end = (k + 1 < nint) ? offs[(size_t)k + 1] - 2 : im.scan_len;
             }
+            if (seg_range) { beg = (size_t)seg_range[0]; end = (size_t)seg_range[1]; } // a part of the stream (one image, no restart interval)
             s.raw_begin = raw_off[i] + beg;
             s.raw_end = raw_off[i] + end;
             const size_t rl = end - beg;
@@ -655,6 +677,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
         {
             d.k1w_mcus = (d.hs * d.vs == 1 ? 64u : 32u) * k1w_mult;
             const uint32_t per_wg = 4u * d.k1w_mcus; // MCUs per write-pass workgroup
+            b->range.per_wg = per_wg;
             d.first_k1w = (uint32_t)k1w_img.size();
             for (uint64_t m = 0; m < wmcu; m += per_wg) k1w_img.push_back((uint32_t)i);
         }
@@ -663,6 +686,8 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
         const uint32_t ns = (d.strips_x * d.nrows + k2_ns - 1) / k2_ns; // workgroups of stage 2
         const int cls = ncomp == 1 ? 4 : (d.hs == 2 && d.vs == 2) ? 0 : (d.hs == 1 && d.vs == 1) ? 1 : (d.hs == 2) ? 2 : 3;
         for (uint32_t s = 0; s < ns; s++) { k2_grp[cls].push_back(s); k2_img[cls].push_back((uint32_t)i); }
+        b->range.cls = (uint32_t)cls;
+        b->range.strips_x = d.strips_x;
         nstrip_total += ns;
         b->scan_bytes += im.scan_len;
         b->coef_bytes += wmcu * d.bpm * 128;
@@ -1047,6 +1072,10 @@ extern "C" int zj_batch_finish(zj_batch *b, uint32_t *status)
     }
     if (b->decoded && b->L.nchunks) {
         if (!hip_ok(c, hipMemcpy(b->h_flags, b->P.flags, 16, hipMemcpyDeviceToHost), "D2H flags")) return ZJ_E_DEVICE;
+        if ((b->h_flags[0] || b->h_flags[1]) && b->range.on) {
+            c->err = "part of a split stream: the walks did not converge, decode the stream whole";
+            return ZJ_E_CHAIN;
+        }
         if (b->h_flags[0] || b->h_flags[1]) {
             // Subsequence records did not converge in the fixed number of fix-up passes: iterate to a
             // fixed point (each pass completes at least one more chunk), then redo everything behind.
@@ -1130,7 +1159,7 @@ extern "C" size_t zj_batch_segments(zj_batch *b, size_t i, uint64_t *ranges, siz
 {
     if (!b || i >= b->n || b->unsupported[i]) return 0;
     const ZjImgDev &d = b->imgs[i];
-    const uint64_t base = d.nseg ? b->segs[d.first_seg].raw_begin : 0; // the first segment starts at the scan's first byte
+    const uint64_t base = b->scan_at[i];
     for (uint32_t k = 0; k < d.nseg && k < cap; k++) {
         ranges[2 * (size_t)k] = b->segs[d.first_seg + k].raw_begin - base;
         ranges[2 * (size_t)k + 1] = b->segs[d.first_seg + k].raw_end - base;
@@ -1202,6 +1231,244 @@ extern "C" int zj_decode_batch(zj_ctx *ctx, const zj_image *imgs, size_t n, cons
     for (void *p : tmp) (void)hipFree(p);
     zj_batch_destroy(b);
     return rc;
+}
+
+// ---------------------------------------------------------------------------------- a stream split over several GPUs
+// An image without restart markers is one serial chain (src/decoder.rs:376-389): nothing in the stream says where an
+// MCU begins or what the DC predictors are until everything before has been decoded.  The chain is cut the way the
+// subsequences of one GPU are: part r starts its walk `lead_bytes` in front of its boundary from a guessed state, and
+// by the boundary its walk has met the true one (self-synchronisation).  What it cannot know on its own -- whether
+// that is so, the raster index of its first MCU and the predictors there -- comes out of one all-gather of a small
+// report per part: the part before says where ITS walk, whose start is already established, sees the first block
+// behind the common boundary and which place in the MCU that block has; if the two parts agree there, everything
+// behind is the same walk.  MCUs belong to the part in whose range they begin.
+#define ZJ_RANGE_TAIL 4096u // raw bytes a part reads beyond its end: more than any MCU can take (10 blocks of at most 1 665 bits, stuffed)
+
+// Kept bytes of raw[a, b) (src/bitstream.rs:37-50: a 00 behind an FF is dropped); a and b do not split such a pair.
+static uint64_t kept_bytes(const uint8_t *raw, uint64_t a, uint64_t b)
+{
+    uint64_t n = b - a;
+    for (uint64_t k = a; k + 1 < b; k++) {
+        const uint8_t *ff = (const uint8_t *)memchr(raw + k, 0xff, (size_t)(b - 1 - k));
+        if (!ff) break;
+        k = (uint64_t)(ff - raw);
+        if (raw[k + 1] == 0x00) { n--; k++; }
+    }
+    return n;
+}
+
+// A byte offset of the scan moved forward until it does not follow an FF (so that it splits no FF 00 pair).
+static uint64_t clear_of_ff(const uint8_t *raw, uint64_t at, uint64_t len)
+{
+    while (at > 0 && at < len && raw[at - 1] == 0xff) at++;
+    return at;
+}
+
+extern "C" zj_batch *zj_batch_create_range(zj_ctx *ctx, const zj_image *img, uint32_t rank, uint32_t nranks, uint32_t lead_bytes, uint32_t flags)
+{
+    if (!ctx) return nullptr;
+    ctx->err_code = ZJ_E_INVALID;
+    if (!img || nranks == 0 || rank >= nranks) { ctx->err = "bad rank"; return nullptr; }
+    if (!zj_image_supported(img) || img->restart_interval != 0) { ctx->err = "stream split: one supported image without restart interval"; return nullptr; }
+    const uint8_t *raw = img->scan;
+    const uint64_t len = img->scan_len;
+    auto boundary = [&](uint32_t r) -> uint64_t { return r >= nranks ? len : clear_of_ff(raw, (len * r / nranks) & ~63ull, len); };
+    const uint64_t bx = rank ? boundary(rank) : 0, by = boundary(rank + 1);
+    const uint64_t lo = (rank && bx > lead_bytes) ? clear_of_ff(raw, bx - lead_bytes, len) : 0;
+    const uint64_t hi = std::min<uint64_t>(len, by + (rank + 1 < nranks ? ZJ_RANGE_TAIL : 0u));
+    if (bx > by || lo > bx) { ctx->err = "stream too short to split"; return nullptr; }
+    const uint64_t seg[2] = {lo, hi};
+    zj_batch *b = batch_create_impl(ctx, img, 1, flags, ZJ_ALLOC_OWN, nullptr, 0, nullptr, 0, nullptr, nullptr, seg);
+    if (!b) return nullptr;
+    b->range.on = true;
+    b->range.rank = rank;
+    b->range.nranks = nranks;
+    b->range.last = rank + 1 == nranks;
+    b->range.x_bits = 8u * kept_bytes(raw, lo, bx);
+    b->range.y_bits = 8u * kept_bytes(raw, lo, by);
+    b->range.stage = 0;
+    return b;
+}
+
+// The first block that begins at or behind bit `x` of the part's stream, from the bitmap and the window counts the
+// walks left: its position, the number of blocks that begin before it (without the segment's bias), and the place in
+// its MCU that the walk gives it (from the state recorded at the end of the window before).
+struct ZjBoundary {
+    bool found;
+    uint64_t pos;
+    uint32_t before, k;
+};
+
+static bool read_boundary(zj_batch *b, uint64_t x, uint32_t pay, uint32_t bias, ZjBoundary *out)
+{
+    zj_ctx *c = b->ctx;
+    const ZjSegDev &sg = b->segs[0];
+    const ZjImgDev &d = b->imgs[0];
+    const uint32_t nwin = std::min<uint64_t>((uint64_t)sg.nsub * sg.nc, ((uint64_t)pay + ZJ_WIN_BITS - 1) / ZJ_WIN_BITS);
+    out->found = false;
+    uint32_t w = (uint32_t)(x / ZJ_WIN_BITS);
+    for (uint32_t tries = 0; tries < 64u && w < nwin; tries++, w++) {
+        uint32_t words[ZJ_WIN_WORDS];
+        if (!hip_ok(c, hipMemcpy(words, b->P.bitmap + sg.out_off + (size_t)w * ZJ_WIN_WORDS * 4u, sizeof words, hipMemcpyDeviceToHost), "D2H bitmap")) return false;
+        uint32_t below = 0;
+        for (uint32_t i = 0; i < ZJ_WIN_WORDS; i++) {
+            for (uint32_t bit = 0; bit < 32u; bit++) {
+                if (!((words[i] >> bit) & 1u)) continue;
+                const uint64_t p = (uint64_t)w * ZJ_WIN_BITS + i * 32u + bit;
+                if (p < x) { below++; continue; }
+                uint32_t wb = 0, rec = 0;
+                if (!hip_ok(c, hipMemcpy(&wb, b->P.wbase + sg.first_win + w, 4, hipMemcpyDeviceToHost), "D2H window base")) return false;
+                if (w > 0) {
+                    const uint32_t q = (w - 1u) / sg.nc, cc = (w - 1u) % sg.nc;
+                    if (!hip_ok(c, hipMemcpy(&rec, b->P.winfo + sg.first_win + zj_rec_index(q, cc, sg.nc, sg.lanes), 4, hipMemcpyDeviceToHost), "D2H record")) return false;
+                }
+                const ZjState st = zj_unpack_state(rec, 0);
+                out->found = true;
+                out->pos = p;
+                out->before = wb - bias + below; // wbase carries the bias the last scan ran with
+                out->k = (st.b + (st.z != 0 ? 1u : 0u) + below) % d.bpm;
+                return true;
+            }
+        }
+    }
+    return true;
+}
+
+extern "C" int zj_batch_range_front(zj_batch *b, zj_range_report *report)
+{
+    if (!b || !report || !b->range.on) return ZJ_E_INVALID;
+    zj_ctx *c = b->ctx;
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return ZJ_E_DEVICE;
+    hipStream_t st = c->stream;
+    const ZjImgDev &d = b->imgs[0];
+    const uint32_t bpm = d.bpm;
+    memset(report, 0, sizeof *report);
+    if (!hip_ok(c, hipMemsetAsync(b->P.status, 0, sizeof(uint32_t), st), "memset status")) return ZJ_E_DEVICE;
+    // the walks, and the block counts per window without a bias
+    b->segs[0].blk_bias = 0;
+    if (!hip_ok(c, hipMemcpyAsync(const_cast<ZjSegDev *>(b->P.segs), &b->segs[0], sizeof(ZjSegDev), hipMemcpyHostToDevice, st), "H2D segment")) return ZJ_E_DEVICE;
+    if (!hip_ok(c, hipMemsetAsync(b->P.blockpos + d.first_block, 0, 16 * sizeof(uint32_t), st), "memset positions")) return ZJ_E_DEVICE;
+    zj_launch_range_sync(b->P, b->L, st);
+    uint32_t pay = 0, flags4[4] = {0, 0, 0, 0};
+    if (!hip_ok(c, hipGetLastError(), "kernel launch") || !hip_ok(c, hipStreamSynchronize(st), "stream sync") ||
+        !hip_ok(c, hipMemcpy(&pay, b->P.seg_payload_bits, 4, hipMemcpyDeviceToHost), "D2H payload") ||
+        !hip_ok(c, hipMemcpy(flags4, b->P.flags, 16, hipMemcpyDeviceToHost), "D2H flags")) return ZJ_E_DEVICE;
+    if (flags4[0]) { c->err = "part of a split stream: the walks did not converge, decode the stream whole"; return ZJ_E_CHAIN; }
+    ZjBoundary bx, by;
+    if (!read_boundary(b, b->range.x_bits, pay, 0, &bx)) return ZJ_E_DEVICE;
+    if (!bx.found) { c->err = "part of a split stream: no block begins behind its boundary"; return ZJ_E_CHAIN; }
+    // Number the blocks so that the first one behind the boundary gets its place in its MCU as its number: every
+    // number behind it is then congruent to the block's place, and what the walks took for blocks in the lead-in gets
+    // numbers below zero (beyond the frame's block count in unsigned arithmetic), which the position pass drops.
+    const uint32_t bias = bx.k - bx.before;
+    b->segs[0].blk_bias = bias;
+    if (!hip_ok(c, hipMemcpyAsync(const_cast<ZjSegDev *>(b->P.segs), &b->segs[0], sizeof(ZjSegDev), hipMemcpyHostToDevice, st), "H2D segment")) return ZJ_E_DEVICE;
+    zj_launch_range_dc(b->P, b->L, st);
+    uint32_t found = 0;
+    if (!hip_ok(c, hipGetLastError(), "kernel launch") || !hip_ok(c, hipStreamSynchronize(st), "stream sync") ||
+        !hip_ok(c, hipMemcpy(&found, b->P.seg_found, 4, hipMemcpyDeviceToHost), "D2H block count")) return ZJ_E_DEVICE;
+    const uint32_t gx = bias + bx.before;
+    uint32_t gy = found;
+    report->start_delta = (int32_t)(bx.pos - b->range.x_bits);
+    report->start_k = gx % bpm;
+    if (!b->range.last) {
+        if (!read_boundary(b, b->range.y_bits, pay, bias, &by)) return ZJ_E_DEVICE;
+        if (!by.found) { c->err = "part of a split stream: no block begins behind its end"; return ZJ_E_CHAIN; }
+        gy = bias + by.before;
+        report->end_delta = (int32_t)(by.pos - b->range.y_bits);
+        report->end_k = gy % bpm;
+    } else {
+        report->end_delta = 0;
+        report->end_k = gy % bpm; // 0 when the stream holds whole MCUs
+    }
+    const uint32_t m_first = (gx + bpm - 1) / bpm, m_end = std::max(m_first, (gy + bpm - 1) / bpm);
+    b->range.m_first_local = m_first;
+    b->range.g_first = m_first * bpm;
+    b->range.g_end = m_end * bpm;
+    if ((uint64_t)b->range.g_end > (uint64_t)d.nblocks) { c->err = "part of a split stream: more blocks than the frame holds"; return ZJ_E_CHAIN; }
+    report->mcus = m_end - m_first;
+    // DC prefix in front of the first MCU owned and behind the last one: per component the value of its last block in
+    // the MCU before
+    auto prefix_at = [&](uint32_t g_mcu_end, uint32_t *pre) -> bool {
+        pre[0] = pre[1] = pre[2] = 0;
+        if (g_mcu_end < bpm) return true;
+        int16_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (!hip_ok(c, hipMemcpy(v, b->P.dcabs + d.first_block + (g_mcu_end - bpm), bpm * sizeof(int16_t), hipMemcpyDeviceToHost), "D2H DC values")) return false;
+        for (uint32_t k = 0; k < bpm; k++) pre[(d.compsel >> (2u * k)) & 3u] = (uint16_t)v[k];
+        return true;
+    };
+    uint32_t end[3];
+    if (!prefix_at(b->range.g_first, b->range.before) || !prefix_at(b->range.g_end, end)) return ZJ_E_DEVICE;
+    for (int k = 0; k < 3; k++) report->dc_sum[k] = (int16_t)(uint16_t)(end[k] - b->range.before[k]);
+    if (report->mcus == 0) report->dc_sum[0] = report->dc_sum[1] = report->dc_sum[2] = 0;
+    b->range.rep = *report;
+    b->range.stage = 1;
+    return ZJ_OK;
+}
+
+extern "C" int zj_batch_range_resolve(zj_batch *b, const zj_range_report *all, uint32_t nranks, uint32_t *mcu_first, uint32_t *mcu_count, uint32_t *row0, uint32_t *nrows)
+{
+    if (!b || !all || !b->range.on || b->range.stage < 1 || nranks != b->range.nranks) return ZJ_E_INVALID;
+    zj_ctx *c = b->ctx;
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return ZJ_E_DEVICE;
+    ZjImgDev &d = b->imgs[0];
+    // the chain of boundaries: part r's walk is the true one if part r - 1's is and both see the same block, at the same
+    // place in its MCU, first behind their common boundary; part 0 starts at the stream's first bit
+    uint64_t mcu0 = 0, before_last = 0;
+    uint32_t pred[3] = {0, 0, 0};
+    if (all[0].start_delta != 0 || all[0].start_k != 0) { c->err = "split stream: the first part does not begin with a block"; return ZJ_E_CHAIN; }
+    for (uint32_t r = 0; r < nranks; r++) {
+        if (r > 0 && (all[r].start_delta != all[r - 1].end_delta || all[r].start_k != all[r - 1].end_k)) {
+            c->err = "split stream: part " + std::to_string(r) + " had not met the true walk at its boundary (lead-in too short for this stream)";
+            return ZJ_E_CHAIN;
+        }
+        if (r < b->range.rank) {
+            mcu0 += all[r].mcus;
+            for (int k = 0; k < 3; k++) pred[k] = (pred[k] + (uint16_t)all[r].dc_sum[k]) & 0xFFFFu;
+        }
+        if (r + 1 < nranks) before_last += all[r].mcus;
+    }
+    // The last part takes what the frame still lacks: behind the last MCU the walks may have taken the padding bits of
+    // the final byte for one more block, so its own count is an upper bound.
+    const uint64_t frame = (uint64_t)d.mcux * d.mcuy;
+    if (before_last > frame || frame - before_last > all[nranks - 1].mcus) { c->err = "split stream: the parts do not add up to the frame's MCUs"; return ZJ_E_CHAIN; }
+    const uint32_t n = b->range.last ? (uint32_t)(frame - before_last) : b->range.rep.mcus;
+    b->range.g_end = b->range.g_first + n * d.bpm;
+    d.mcu_lo = (uint32_t)mcu0;
+    d.mcu_hi = (uint32_t)mcu0 + n;
+    d.mcu_shift = (uint32_t)mcu0 - b->range.m_first_local;
+    d.row0 = n ? d.mcu_lo / d.mcux : 0;
+    d.nrows = n ? (d.mcu_hi + d.mcux - 1) / d.mcux - d.row0 : 0;
+    for (int k = 0; k < 3; k++) b->range.off[k] = (pred[k] - b->range.before[k]) & 0xFFFFu;
+    b->L.nk1w = (n + b->range.per_wg - 1) / b->range.per_wg;
+    b->L.k2_count[b->range.cls] = (b->range.strips_x * d.nrows + b->P.k2_ns - 1) / b->P.k2_ns;
+    if (!hip_ok(c, hipMemcpyAsync(const_cast<ZjImgDev *>(b->P.imgs), &d, sizeof(ZjImgDev), hipMemcpyHostToDevice, c->stream), "H2D image")) return ZJ_E_DEVICE;
+    if (!hip_ok(c, hipStreamSynchronize(c->stream), "stream sync")) return ZJ_E_DEVICE;
+    if (mcu_first) *mcu_first = d.mcu_lo;
+    if (mcu_count) *mcu_count = n;
+    if (row0) *row0 = d.row0;
+    if (nrows) *nrows = d.nrows;
+    b->range.stage = 2;
+    return ZJ_OK;
+}
+
+extern "C" int zj_batch_range_decode(zj_batch *b, uint8_t *rgb, size_t stride)
+{
+    if (!b || !b->range.on || b->range.stage < 2) return ZJ_E_INVALID;
+    zj_ctx *c = b->ctx;
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return ZJ_E_DEVICE;
+    if (b->range.stage == 2) { // the DC values are corrected once
+        zj_launch_range_write(b->P, b->L, c->stream, b->range.g_first, b->range.g_end, b->range.off);
+        b->range.stage = 3;
+    } else {
+        const uint32_t zero[3] = {0, 0, 0};
+        zj_launch_range_write(b->P, b->L, c->stream, 0, 0, zero);
+    }
+    if (!hip_ok(c, hipGetLastError(), "kernel launch")) return ZJ_E_DEVICE;
+    b->entropy_launched = true;
+    uint8_t *r1[1] = {b->imgs[0].nrows ? rgb : nullptr};
+    size_t s1[1] = {stride};
+    return decode_pixels(b, r1, s1, c->stream);
 }
 
 // ---------------------------------------------------------------------------------- no-allocation entry point

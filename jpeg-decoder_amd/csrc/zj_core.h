@@ -111,8 +111,11 @@ struct ZjImgDev {
                             // bit 2: so do its pair tables
     uint32_t first_k1w;     // first workgroup of the write pass
     uint32_t k1w_mcus;      // MCUs per wavefront of the write pass (a multiple of 64)
-    uint32_t row0, nrows;   // MCU rows whose coefficients and pixels are produced (the entropy front always covers the
-                            // whole image); the pixel buffer begins at MCU row row0
+    uint32_t row0, nrows;   // MCU rows whose pixels are produced; the pixel buffer begins at MCU row row0
+    uint32_t mcu_lo, mcu_hi; // MCUs (raster index in the image) whose coefficients the write pass produces: those of the
+                            // rows above, or the MCUs that begin in this rank's part of a stream split over several GPUs
+    uint32_t mcu_shift;     // such a part numbers the blocks it finds from its own first one: MCU m of the image is MCU
+                            // m - mcu_shift of the position list, the DC values and the DC symbol lengths (0 otherwise)
 };
 
 struct ZjSegDev {
@@ -131,6 +134,11 @@ struct ZjSegDev {
     uint32_t first_ptile;        // first workgroup of the position pass (256 windows each)
     uint32_t first_tile, ntiles; // tiles of the unstuff pass (15 KiB of raw bytes each, from raw_begin & ~15)
     uint32_t first_dtile, ndtiles; // tiles of the DC scan (256 MCUs each, at least one)
+    uint32_t blk_bias;           // number given to the first block found in the stream: 0, or -- in a part of a split stream,
+                                 // which begins somewhere inside an MCU -- what gives the first block behind the part's
+                                 // boundary its place in its MCU as its number (negative, modulo 2^32, when the walks
+                                 // found blocks in the lead-in: those numbers fall outside the frame and are dropped)
+    uint32_t pad;
 };
 
 // Window records.  Every segment's unstuffed stream is cut into windows of ZJ_WIN_BITS bits; a

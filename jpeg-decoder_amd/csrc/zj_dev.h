@@ -104,5 +104,8 @@ void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream_t st, hipE
 void zj_launch_fix_only(const ZjParams &P, const ZjLaunch &L, hipStream_t st);
 void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipStream_t st);
 void zj_launch_stage2(const ZjParams &P, const ZjLaunch &L, hipStream_t st, hipEvent_t *ev);
+void zj_launch_range_sync(const ZjParams &P, const ZjLaunch &L, hipStream_t st);
+void zj_launch_range_dc(const ZjParams &P, const ZjLaunch &L, hipStream_t st);
+void zj_launch_range_write(const ZjParams &P, const ZjLaunch &L, hipStream_t st, uint32_t g0, uint32_t g1, const uint32_t *off);
 void zj_launch_dequant(const ZjParams &P, uint32_t ii, uint32_t nblocks, int16_t *dst, hipStream_t st);
 }

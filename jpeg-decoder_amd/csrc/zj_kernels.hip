@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
     const uint32_t nwin = min(sg.nsub * NC, (pay + ZJ_WIN_BITS - 1u) / ZJ_WIN_BITS);
     const uint32_t *rec = P.winfo + sg.first_win;
     uint32_t *wb = P.wbase + sg.first_win;
-    uint32_t carry = 0;
+    uint32_t carry = sg.blk_bias;
     if (P.nseg >= 256u && sg.lanes == 64u && sg.nsub <= 128u) {
         // Enough segments to fill the GPU, and one or two whole chunks of 64 subsequences (a longer segment is a longer
         // chain of tiles than of the plain steps below): the records lie [chunk][window of
@@ -1059,6 +1059,21 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan_small(ZjParams P, uint32_t 
     zj_dc_tile_store(da, lane, nmcu, bpm, out);
 }
 
+// A part of a stream that was split over several GPUs scans its DC differences from its own first block, where the
+// predictors are unknown (and what it found in its lead-in is no block at all).  When the parts before it have reported
+// their sums (src/decoder.rs:199-200 carries the predictors from MCU to MCU; wrapping i16 addition is associative),
+// every value of the blocks it owns is corrected by one constant per component.
+__global__ __launch_bounds__(256) void zj_k1d_add_offset(ZjParams P, uint32_t ii, uint32_t g0, uint32_t g1, uint32_t off0, uint32_t off1, uint32_t off2)
+{
+    const ZjImgDev &im = P.imgs[ii];
+    const uint32_t g = g0 + blockIdx.x * 256u + threadIdx.x;
+    if (g >= g1) return;
+    const uint32_t c = (im.compsel >> (2u * (g % im.bpm))) & 3u;
+    const uint32_t off = c == 0u ? off0 : (c == 1u ? off1 : off2);
+    int16_t *da = P.dcabs + im.first_block;
+    da[g] = (int16_t)((uint32_t)(uint16_t)da[g] + off);
+}
+
 // ---------------------------------------------------------------------------------- k1w: write
 // One lane per block.  A wavefront owns a run of MCUs and works through it in rounds of 64 blocks of
 // one kind -- all luma blocks first, then all chroma blocks -- because luma blocks carry several
@@ -1234,8 +1249,8 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
     const uint16_t *glut = P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES + 2u * ZJ_TBL_ENTRIES; // the AC tables in their 16-bit form
     const uint32_t shl = nl == 4u ? 2u : (nl == 2u ? 1u : 0u);     // log2 of the luma blocks per MCU
     const uint32_t M = im.k1w_mcus;                                // MCUs per wavefront
-    const uint32_t m0 = im.row0 * im.mcux + ((blockIdx.x - im.first_k1w) * 4u + wave) * M; // first MCU of this wavefront
-    const uint32_t nmcu = min(im.nblocks / bpm, (im.row0 + im.nrows) * im.mcux); // end of the rows that are wanted
+    const uint32_t m0 = im.mcu_lo + ((blockIdx.x - im.first_k1w) * 4u + wave) * M; // first MCU of this wavefront
+    const uint32_t nmcu = im.mcu_hi;                                               // end of the MCUs that are wanted
     uint32_t *row32 = &tile[wave][lane * 33u];
     int16_t *row = reinterpret_cast<int16_t *>(row32);
     uint32_t *col = &scol[wave][lane];
@@ -1295,7 +1310,7 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
             const uint32_t mcu = m0 + (qi >> sh);
             d.kb = (luma ? 0u : nl) + (qi & ((1u << sh) - 1u));
             d.valid = mcu < nmcu;
-            const uint32_t gl = d.valid ? mcu * bpm + d.kb : 0u; // block index inside the image
+            const uint32_t gl = d.valid ? (mcu - im.mcu_shift) * bpm + d.kb : 0u; // block index in the position list
             const uint32_t g = im.first_block + gl;
             uint32_t gs = gl, fnd = found;
             d.pay = pay;
@@ -2129,6 +2144,34 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
+}
+
+// The halves of stage 1 for a part of a split stream (zj_batch_range_*): up to the block counts; from the block counts
+// to the DC values; the correction of the DC values and the coefficients.
+extern "C" void zj_launch_range_sync(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
+{
+    hipMemsetAsync(P.flags, 0, 8, st);
+    hipMemsetAsync(P.tile_status, 0, (size_t)L.ntiles * sizeof(uint64_t) + (size_t)L.nseg * sizeof(uint32_t), st);
+    if (L.ntiles) hipLaunchKernelGGL((zj_k0_unstuff<128, 31, false>), dim3(L.ntiles), dim3(128), 0, st, P, 0u);
+    if (L.nsmall) hipLaunchKernelGGL((zj_k0_unstuff<64, 15, true>), dim3(L.nsmall), dim3(64), 0, st, P, L.ntiles);
+    hipLaunchKernelGGL(zj_k1a_sync, dim3(L.nchunks / 4), dim3(256), 0, st, P);
+    if (L.npacked) hipLaunchKernelGGL(zj_k1a_sync_packed, dim3(L.nchunks / 4), dim3(256), 0, st, P);
+    for (int i = 0; i < L.fix_iters; i++) hipLaunchKernelGGL(zj_k1b_fix, dim3(L.nchunks / 4), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
+}
+
+extern "C" void zj_launch_range_dc(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
+{
+    hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P); // again, from the segment's bias
+    if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(zj_k1c_dcdiff, dim3((L.nblk256 + ZJ_K1C_NB - 1) / ZJ_K1C_NB), dim3(256), 0, st, P, L.nblk256);
+    zj_launch_dcscan(P, L, st);
+}
+
+extern "C" void zj_launch_range_write(const ZjParams &P, const ZjLaunch &L, hipStream_t st, uint32_t g0, uint32_t g1, const uint32_t *off)
+{
+    if (g1 > g0) hipLaunchKernelGGL(zj_k1d_add_offset, dim3((g1 - g0 + 255u) / 256u), dim3(256), 0, st, P, 0u, g0, g1, off[0], off[1], off[2]);
+    if (L.nk1w) hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
 }
 
 extern "C" void zj_launch_markers(const ZjMarkParams &M, hipStream_t st)

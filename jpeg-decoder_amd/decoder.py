@@ -333,6 +333,115 @@ class Batch:
             pass
 
 
+class ChainError(DecodeError):
+    """The parts of a split stream do not join up (ZJ_E_CHAIN): decode the stream whole, or with row windows."""
+
+    def __init__(self, message):
+        super().__init__("chain", message)
+
+
+class RangeBatch:
+    """Part `rank` of `nranks` of one image without restart markers (zj_batch_create_range): unstuffing, walks, block
+    positions and DC differences cover this part's bytes only (plus `lead_bytes` in front of its boundary).  Use:
+        report = part.front()                  # bytes, to be all-gathered by the caller
+        first, count, row0, nrows = part.resolve(reports_of_all_parts)    # ChainError: fall back to Batch(rows=...)
+        part.decode(window)                    # window: uint8 tensor that begins at MCU row row0
+        part.finish()
+    """
+
+    REPORT_BYTES = C.sizeof(B.zj_range_report)
+
+    def __init__(self, ctx: Context, image, rank, nranks, lead_bytes=16384, subseq_bits=0):
+        self.ctx, self.image, self.rank, self.nranks = ctx, image, rank, nranks
+        self.n = 1
+        self._img = image.image
+        self.h = B.lib().zj_batch_create_range(ctx.h, C.byref(self._img), rank, nranks, lead_bytes, subseq_bits)
+        if not self.h:
+            raise DecodeError("device", "zj_batch_create_range failed: " + ctx.last_error())
+        self.window = None  # (first MCU, MCUs, first MCU row, MCU rows) once resolved
+        self._rgb = None
+
+    def front(self) -> bytes:
+        rep = B.zj_range_report()
+        rc = B.lib().zj_batch_range_front(self.h, C.byref(rep))
+        if rc == B.ZJ_E_CHAIN:
+            raise ChainError(self.ctx.last_error())
+        if rc != B.ZJ_OK:
+            raise DecodeError("device", self.ctx.last_error())
+        return bytes(rep)
+
+    def resolve(self, reports):
+        """reports: the `nranks` reports in rank order (bytes each, or one bytes object of all of them)."""
+        blob = reports if isinstance(reports, (bytes, bytearray)) else b"".join(bytes(r) for r in reports)
+        if len(blob) != self.nranks * self.REPORT_BYTES:
+            raise ValueError("one report per part")
+        arr = (B.zj_range_report * self.nranks).from_buffer_copy(blob)
+        v = [C.c_uint32() for _ in range(4)]
+        rc = B.lib().zj_batch_range_resolve(self.h, arr, self.nranks, *[C.byref(x) for x in v])
+        if rc == B.ZJ_E_CHAIN:
+            raise ChainError(self.ctx.last_error())
+        if rc != B.ZJ_OK:
+            raise DecodeError("device", self.ctx.last_error())
+        self.window = tuple(x.value for x in v)
+        return self.window
+
+    def window_height(self):
+        im = self.image
+        mh = 8 * max(im.image.vsamp[0], 1)
+        _, _, row0, nrows = self.window
+        return min(nrows * mh, im.height - row0 * mh) if nrows else 0
+
+    def decode(self, rgb):
+        """rgb: 2-D uint8 CUDA tensor of at least window_height() rows; its row 0 is the first pixel row of MCU row row0."""
+        if self.window is None:
+            raise DecodeError("device", "resolve() first")
+        ptr, stride = None, 0
+        if self.window[3]:
+            check_output_tensor(rgb, self.image, self.ctx.device, self.window_height())
+            ptr, stride = rgb.data_ptr(), rgb.stride(0)
+        self._rgb = rgb
+        rc = B.lib().zj_batch_range_decode(self.h, ptr, stride)
+        if rc != B.ZJ_OK:
+            raise DecodeError("device", self.ctx.last_error())
+
+    def finish(self):
+        st = np.zeros(1, np.uint32)
+        rc = B.lib().zj_batch_finish(self.h, st.ctypes.data_as(C.POINTER(C.c_uint32)))
+        if rc == B.ZJ_E_CHAIN:
+            raise ChainError(self.ctx.last_error())
+        if rc != B.ZJ_OK:
+            raise DecodeError("device", self.ctx.last_error())
+        return st
+
+    def coefficients(self):
+        """int16 [MCUs owned * blocks per MCU, 64], zig-zag quantised: the coefficients of the MCUs this part owns."""
+        nb = self.image.nblocks
+        out = np.empty((nb, 64), np.int16)
+        rc = B.lib().zj_batch_export_coef(self.h, 0, out.ctypes.data_as(C.c_void_p), None, B.ZJ_MEM_HOST)
+        if rc != B.ZJ_OK:
+            raise DecodeError("device", self.ctx.last_error())
+        bpm = nb // B.lib().zj_image_mcus(C.byref(self._img))
+        return out[self.window[0] * bpm: (self.window[0] + self.window[1]) * bpm]
+
+    def segments(self):
+        """(begin, end) byte offsets inside the scan of the bytes this part reads."""
+        buf = (C.c_uint64 * 2)()
+        B.lib().zj_batch_segments(self.h, 0, buf, 1)
+        return int(buf[0]), int(buf[1])
+
+    def close(self):
+        if self.h:
+            B.lib().zj_batch_destroy(self.h)
+            self.h = None
+        self._rgb = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def check_output_tensor(t, im, device, height=None):
     """A pixel output must be a 2-D uint8 tensor on the context's GPU with unit inner stride, at least
     `height` rows and a row pitch of at least 3 * width bytes: the kernels write exactly that region."""

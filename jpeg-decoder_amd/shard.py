@@ -6,8 +6,12 @@
 * One huge restart-marked image shards by contiguous bands of MCU rows that begin and end on
   restart-interval boundaries; each rank decodes its band as an ordinary image and the bands are
   gathered on the root rank.
-* An image without restart markers does not shard (serial DC chain, unknown bit alignment at any
-  cut): replicas only.
+* An image without restart markers is one serial chain (unknown bit alignment and DC predictors at any
+  cut).  It is split by bytes: every rank walks its part of the stream from a lead-in, one all-gather of a
+  32-byte report per rank joins the parts up (RangeBatch), and every rank then owns a run of MCUs in raster
+  order -- not whole rows, so its pixels are gathered as rectangles (mcu_range_pieces).  When the parts do not
+  join up (a lead-in shorter than the stream needs to synchronise), every rank repeats the entropy front and
+  takes a window of rows instead (Batch(rows=...)).
 """
 import heapq
 
@@ -83,4 +87,66 @@ def gather_bands(local_band, band_shapes, rank, world_size, root=0, group=None):
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+    return out
+
+
+def mcu_range_pieces(m0, n, mcux, mw, mh, width, height):
+    """Pixel rectangles (y0, y1, xb0, xb1) -- pixel rows [y0, y1), byte columns [xb0, xb1) of an RGB8 row -- that
+    the MCUs [m0, m0 + n) in raster order cover, clipped to the image: at most a partial first MCU row, a run of
+    whole rows and a partial last row."""
+    out = []
+
+    def rect(row, x0, x1):
+        y0, y1 = row * mh, min((row + 1) * mh, height)
+        xb0, xb1 = min(x0 * mw, width) * 3, min(x1 * mw, width) * 3
+        if y1 > y0 and xb1 > xb0:
+            out.append((y0, y1, xb0, xb1))
+
+    m, end = m0, m0 + n
+    if m < end and m % mcux:
+        stop = min(end, (m // mcux + 1) * mcux)
+        rect(m // mcux, m % mcux, stop - (m // mcux) * mcux)
+        m = stop
+    if end - m >= mcux:
+        r0, r1 = m // mcux, end // mcux
+        y0, y1 = r0 * mh, min(r1 * mh, height)
+        if y1 > y0:
+            out.append((y0, y1, 0, width * 3))
+        m = r1 * mcux
+    if m < end:
+        rect(m // mcux, 0, end - m)
+    return out
+
+
+def pack_pieces(window, y_origin, pieces):
+    """The rectangles `pieces` of `window` (a 2-D uint8 tensor whose row 0 is pixel row y_origin) as one flat tensor."""
+    import torch
+    parts = [window[y0 - y_origin: y1 - y_origin, xb0:xb1].reshape(-1) for (y0, y1, xb0, xb1) in pieces]
+    return torch.cat(parts) if parts else window.new_empty(0)
+
+
+def pieces_bytes(pieces):
+    return sum((y1 - y0) * (xb1 - xb0) for (y0, y1, xb0, xb1) in pieces)
+
+
+def unpack_pieces(full, flat, pieces):
+    """Inverse of pack_pieces into the assembled image `full` (row 0 = pixel row 0)."""
+    at = 0
+    for (y0, y1, xb0, xb1) in pieces:
+        nb = (y1 - y0) * (xb1 - xb0)
+        full[y0:y1, xb0:xb1].copy_(flat[at: at + nb].reshape(y1 - y0, xb1 - xb0))
+        at += nb
+
+
+def split_windows(reports, frame_mcus):
+    """(first MCU, MCUs) of every part from the gathered reports (bytes each), as zj_batch_range_resolve assigns
+    them: every part the MCUs it reports, the last part what the frame still lacks."""
+    import struct
+    mcus = [struct.unpack_from("<I", bytes(r), 16)[0] for r in reports]
+    out, at = [], 0
+    for k, n in enumerate(mcus):
+        if k == len(mcus) - 1:
+            n = frame_mcus - at
+        out.append((at, n))
+        at += n
     return out

@@ -190,6 +190,85 @@ def test_rows_of_images_without_restart_markers(ctx):
     b.close()
 
 
+def decode_split(ctx, data, nparts, lead_bytes, subseq_bits=0):
+    """One image without restart markers decoded as `nparts` parts of its stream, the way `nparts` ranks would: every
+    part's front on its own, the reports exchanged (here: a list), every part resolved and decoded, the pixels of the
+    MCUs each part owns assembled.  Returns (rgb HxWx3, coefficients [blocks, 64], parts' windows, byte ranges)."""
+    import torch
+    p = J.ParsedImage(data)
+    hs, vs = p.image.hsamp[0], p.image.vsamp[0]
+    mcux, mcuy, mw, mh = shard.mcu_geometry(p.width, p.height, hs, vs)
+    parts = [J.RangeBatch(ctx, p, r, nparts, lead_bytes, subseq_bits) for r in range(nparts)]
+    try:
+        reports = [q.front() for q in parts]
+        wins = [q.resolve(reports) for q in parts]
+        assert [w[:2] for w in wins] == shard.split_windows(reports, mcux * mcuy)
+        pitch = (p.width * 3 + 15) // 16 * 16
+        full = torch.zeros((p.height, pitch), dtype=torch.uint8, device="cuda:0")
+        coef = np.zeros((p.nblocks, 64), np.int16)
+        bpm = p.nblocks // (mcux * mcuy)
+        for q, (m0, n, row0, nrows) in zip(parts, wins):
+            win = torch.empty((max(q.window_height(), 1), pitch), dtype=torch.uint8, device="cuda:0")
+            q.decode(win)
+            assert not q.finish().any()
+            pieces = shard.mcu_range_pieces(m0, n, mcux, mw, mh, p.width, p.height)
+            shard.unpack_pieces(full, shard.pack_pieces(win, row0 * mh, pieces), pieces)
+            coef[m0 * bpm: (m0 + n) * bpm] = q.coefficients()
+        rgb = full[:, : p.width * 3].reshape(p.height, p.width, 3).cpu().numpy()
+        return rgb, coef, wins, [q.segments() for q in parts]
+    finally:
+        for q in parts:
+            q.close()
+
+
+def test_stream_without_restart_markers_split_into_parts(ctx):
+    """The serial chain of src/decoder.rs:376-389 cut into parts by bytes: every part unstuffs and walks only its own
+    bytes plus a lead-in, starts somewhere inside an MCU at an arbitrary bit with unknown predictors, and the
+    exchange of one small report per part gives it its first MCU and its predictors.  The assembled result must be
+    the oracle's, pixels and coefficients, for 4:4:4 and subsampled layouts, with parts that own whole rows, pieces of
+    rows, or nothing at all."""
+    cases = [(fixture_bytes("large.jpg"), (2, 3, 8), 16384), (fixture_bytes("porsche.jpg"), (2, 5), 4096),
+             (synth.encode(1000, 600, 2, 2, 90, 0, 91, 0), (2, 4, 7), 8192), (synth.encode(640, 480, 2, 1, 85, 2, 92, 0), (3,), 8192),
+             (synth.encode(333, 211, 0, 0, 90, 0, 93, 0), (2,), 2048)]
+    for data, counts, lead in cases:
+        ref = oracle.decode(data)
+        scan_len = oracle.probe(data).scan_len
+        for nparts in counts:
+            rgb, coef, wins, ranges = decode_split(ctx, data, nparts, lead)
+            assert np.array_equal(coef, ref.qcoef), (len(data), nparts)
+            assert np.array_equal(rgb, ref.rgb), (len(data), nparts)
+            # every part reads its share of the stream plus the lead-in and a short tail, not the whole stream
+            for r, (lo, hi) in enumerate(ranges):
+                assert hi - lo <= scan_len // nparts + lead + 4096 + 128, (r, lo, hi)
+            assert sum(w[1] for w in wins) == ref.info.mcux * ref.info.mcuy
+
+
+def test_split_parts_that_do_not_join_up_are_refused(ctx):
+    """A lead-in far shorter than the distance this stream needs to synchronise (a flat image: one short code per
+    block, any bit looks like a block start): the chain of boundaries does not validate, every part learns so from
+    the same reports, and the caller falls back to row windows -- nothing is decoded from a wrong start."""
+    data = fixture_bytes("test-baseline.jpg")
+    p = J.ParsedImage(data)
+    parts = [J.RangeBatch(ctx, p, r, 4, 64) for r in range(4)]
+    try:
+        reports = [q.front() for q in parts]
+        refused = 0
+        for q in parts:
+            with pytest.raises(J.ChainError):
+                q.resolve(reports)
+            refused += 1
+        assert refused == 4
+    except J.ChainError:
+        pass  # a part may already find no block behind its boundary: the same refusal, one call earlier
+    finally:
+        for q in parts:
+            q.close()
+    # with a lead-in that covers the distance the same stream splits fine
+    ref = oracle.decode(data)
+    rgb, coef, _, _ = decode_split(ctx, data, 4, 65536)
+    assert np.array_equal(coef, ref.qcoef) and np.array_equal(rgb, ref.rgb)
+
+
 def test_random_images_match_the_oracle(ctx):
     """Three batches of the randomised sweep (tests/sweep_parity.py): 64 random valid images each -- sizes, sampling
     layouts, qualities, content classes, restart intervals, table ids -- decoded with two subsequence sizes."""

@@ -56,6 +56,25 @@ def test_c5_two_ranks_bands_of_a_restart_marked_image():
 
 
 def test_c6_two_ranks_image_without_restart_markers():
+    """The stream split by bytes: each rank unstuffs and walks its own part plus the lead-in only."""
     r = run_bench("--config", "c6")
     assert r["config"]["workload"].startswith("c6:") and r["scaling"] == "strong"
+    assert "split by bytes" in r["config"]["workload"] and "FELL BACK" not in r["config"]["workload"]
+    assert r["config"]["scan_bytes_read_by_rank0"] < 0.6 * r["config"]["scan_bytes"]
+    wins = r["config"]["mcus_first_count_per_rank"]
+    assert len(wins) == 2 and wins[0][0] == 0 and wins[1][0] == wins[0][1] and wins[0][1] + wins[1][1] == (7680 // 8) * (4320 // 8)
+    assert r["verified"]["equal"] and r["verified"]["equals_oracle"]
+
+
+def test_c6_two_ranks_falls_back_when_the_parts_do_not_join_up():
+    """A lead-in of 16 bytes is shorter than any stream needs to synchronise: every rank learns from the same reports
+    that the chain does not validate, and the run repeats the entropy front on every rank instead."""
+    r = run_bench("--config", "c6", "--lead-bytes", "16")
+    assert "FELL BACK" in r["config"]["workload"]
+    assert r["verified"]["equal"] and r["verified"]["equals_oracle"]
+
+
+def test_c6_two_ranks_row_windows_on_request():
+    r = run_bench("--config", "c6", "--c6-rows")
+    assert "entropy front repeated" in r["config"]["workload"]
     assert r["verified"]["equal"] and r["verified"]["equals_oracle"]

@@ -120,3 +120,48 @@ def test_bands_decoded_alone_tile_the_image():
             bands = shard.band_rows(mcux, mcuy, ri, world)
             rows = [_decode_band_with_oracle(data, parsed, r0, n) for (r0, n) in bands if n]
             assert np.array_equal(np.concatenate(rows, 0), full), (w, h, world)
+
+
+def test_mcu_range_pieces_cover_exactly_the_mcus():
+    """The rectangles of a run of MCUs in raster order (what a part of a split stream owns), against a brute-force
+    painting MCU by MCU, for runs that begin and end inside rows, cover whole rows, or are empty."""
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        mw, mh = int(rng.choice([8, 16])), int(rng.choice([8, 16]))
+        w, h = int(rng.integers(1, 150)), int(rng.integers(1, 150))
+        mcux, mcuy, _, _ = shard.mcu_geometry(w, h, mw // 8, mh // 8)
+        tot = mcux * mcuy
+        m0 = int(rng.integers(0, tot))
+        n = int(rng.integers(0, tot - m0 + 1))
+        got = np.zeros((h, w * 3), np.int32)
+        pieces = shard.mcu_range_pieces(m0, n, mcux, mw, mh, w, h)
+        assert len(pieces) <= 3
+        for (y0, y1, a, b) in pieces:
+            got[y0:y1, a:b] += 1
+        want = np.zeros((h, w * 3), np.int32)
+        for m in range(m0, m0 + n):
+            r, c = divmod(m, mcux)
+            want[r * mh:(r + 1) * mh, c * mw * 3:(c + 1) * mw * 3] += 1
+        assert np.array_equal(got, want)
+        assert shard.pieces_bytes(pieces) == int(want.sum())
+
+
+def test_pieces_round_trip_and_windows_from_reports():
+    import struct
+    import torch
+    w, h, mw, mh = 100, 70, 16, 16
+    mcux, mcuy, _, _ = shard.mcu_geometry(w, h, 2, 2)
+    img = torch.arange(h * w * 3, dtype=torch.int64).remainder(251).to(torch.uint8).reshape(h, w * 3)
+    full = torch.zeros_like(img)
+    reports = [struct.pack("<iIiIIhhhHI", 0, 0, 5, 1, 9, 0, 0, 0, 0, 0), struct.pack("<iIiIIhhhHI", 5, 1, 2, 0, 17, 0, 0, 0, 0, 0),
+               struct.pack("<iIiIIhhhHI", 2, 0, 0, 0, 99, 0, 0, 0, 0, 0)]
+    wins = shard.split_windows(reports, mcux * mcuy)
+    assert wins == [(0, 9), (9, 17), (26, mcux * mcuy - 26)]
+    for (m0, n) in wins:
+        pieces = shard.mcu_range_pieces(m0, n, mcux, mw, mh, w, h)
+        row0 = m0 // mcux
+        window = img[row0 * mh:]  # what a rank holds: its MCU rows from row0 on
+        flat = shard.pack_pieces(window, row0 * mh, pieces)
+        assert flat.numel() == shard.pieces_bytes(pieces)
+        shard.unpack_pieces(full, flat, pieces)
+    assert torch.equal(full, img)

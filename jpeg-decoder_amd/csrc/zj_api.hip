@@ -420,7 +420,12 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
         const uint64_t lanes = (uint64_t)cus * 16u * 64u;
-        subbits = 1024;
+        // One window for a very small input (what counts there is the chain of window steps of a lone wavefront, and a
+        // second window of its own is one more step for every lane; measured: 0.167 -> 0.154 ms for a 600x200 image).
+        // Not beyond: a chunk of 64 subsequences has to be longer than the distance a wrong guess survives, or the fix pass
+        // runs through whole chunks and the decode call is repeated with the exhaustive loop -- 32 Kbit chunks are enough
+        // for photographs, not for large flat images; and from sixteen 1080p images on, longer subsequences do less work twice.
+        subbits = bits < (4u << 20) ? ZJ_WIN_BITS : 1024u;
         while (subbits < 65536u && (uint64_t)subbits * lanes < bits) subbits *= 2u;
     }
     if (subbits < ZJ_WIN_BITS || subbits > (1u << 20)) { ctx->err = "subsequence bits must be in 512..1048576"; zj_batch_destroy(b); return nullptr; }
@@ -433,6 +438,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     std::vector<uint16_t> luts;
     std::vector<ZjCanon> canons;
     std::vector<uint16_t> qts;
+    std::vector<uint8_t> set_partner; // [table set][DC id] AC table id that follows, or 0xFF
     std::map<std::string, uint32_t> lut_ids, qt_ids;
     std::vector<size_t> raw_off(n, 0);
     size_t raw_total = 0, ust_total = 0;
@@ -534,6 +540,17 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
                 if (t4[t]) key.append((const char *)t4[t], sizeof(zj_huff));
                 else key.append(sizeof(zj_huff), '\0');
             }
+            // Which AC table follows each DC table in this image's blocks (0, 1, or 0xFF: none or not the same for all
+            // components that use it): the DC pair entries hold the block's first AC symbol, so the pairing is part of
+            // what a table set is.
+            uint8_t partner[2] = {0xFF, 0xFF};
+            for (int dcid = 0; dcid < 2; dcid++) {
+                int a = -1;
+                for (uint32_t c = 0; c < ncomp; c++)
+                    if (im.td[c] == dcid) a = (a == -1 || a == im.ta[c]) ? im.ta[c] : -2;
+                if (a >= 0) partner[dcid] = (uint8_t)a;
+            }
+            key.append((const char *)partner, 2);
             auto it = lut_ids.find(key);
             if (it == lut_ids.end()) {
                 const uint32_t id = (uint32_t)(luts.size() / ZJ_SET_ENTRIES);
@@ -545,6 +562,8 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
                     if (t4[t]) ok = zj_build_table(t4[t], tbl, &canons[(size_t)id * 4 + t], l2_cap) && ok;
                     else { memset(tbl, 0, sizeof(uint16_t) * ZJ_TBL_ENTRIES); memset(&canons[(size_t)id * 4 + t], 0, sizeof(ZjCanon)); }
                 }
+                if (ok) { set_partner.push_back(partner[0]); set_partner.push_back(partner[1]); }
+                else { luts.resize((size_t)id * ZJ_SET_ENTRIES); canons.resize((size_t)id * 4); }
                 it = lut_ids.emplace(key, ok ? id : ZJ_NONE).first;
             }
             if (it->second == ZJ_NONE) { b->unsupported[i] = 1; d.flags = 0; d.nblocks = 0; continue; }
@@ -732,7 +751,8 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     std::vector<uint8_t> pair_needs_canon(luts.size() / ZJ_SET_ENTRIES, 0);
     for (size_t t = 0; t < luts.size() / ZJ_TBL_ENTRIES; t++) {
         uint32_t *pt = &ptabs[t * ZJ_PT_ENTRIES];
-        (void)zj_build_pair_table(&canons[t], (t & 3u) < 2u, pt);
+        const uint8_t pa = (t & 3u) < 2u ? set_partner[(t / 4u) * 2u + (t & 1u)] : 0xFF;
+        (void)zj_build_pair_table(&canons[t], (t & 3u) < 2u, pt, pa != 0xFF ? &canons[(t / 4u) * 4u + 2u + pa] : nullptr);
         for (uint32_t e = 0; e < (uint32_t)ZJ_PL1_SIZE; e++) {
             if (!(pt[e] & 0x80000000u)) continue;
             if (l2_cap == 0) pt[e] = 0x80000000u; // the testing aid that drops the second level applies here too
@@ -764,12 +784,22 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     P.canons = dev_upload(b, canons);
     P.qts = dev_upload(b, qts);
     P.raw = raw;
-    P.status = dev_alloc<uint32_t>(b, n, true);
-    P.flags = dev_alloc<uint32_t>(b, 4, true);
+    // what every decode call clears, in one block so that it is one fill: flags, status words, the unstuff pass's look-back
+    // words and tickets
+    const size_t nbig_tiles = tile_seg.size() - small_seg.size();
+    const size_t status_words = align_up(n ? n : 1, 4);
+    const size_t clear_bytes = 16 + status_words * 4 + (nbig_tiles + 1) * 8 + (b->segs.size() + 2) * 4;
+    uint8_t *clear_block = dev_alloc<uint8_t>(b, clear_bytes, true);
+    P.flags = reinterpret_cast<uint32_t *>(clear_block);
+    P.status = clear_block ? reinterpret_cast<uint32_t *>(clear_block + 16) : nullptr;
+    P.tile_status = clear_block ? reinterpret_cast<uint64_t *>(clear_block + 16 + status_words * 4) : nullptr;
+    P.seg_ticket = clear_block ? reinterpret_cast<uint32_t *>(P.tile_status + nbig_tiles + 1) : nullptr;
+    P.counters = dev_alloc<uint32_t>(b, 4, true);
+    b->L.clear_bytes = clear_bytes;
     b->d_rgb = dev_alloc<uint8_t *>(b, n, true);
     b->d_stride = dev_alloc<size_t>(b, n, true);
     ok = P.imgs && P.segs && P.chunk_seg && P.blk256_img && P.k1w_img && P.strip_img && P.strip_img_img && P.luts && P.wluts && P.ptabs && P.wtabs && P.wt_info && P.canons && P.qts &&
-         P.ptile_seg && P.tile_seg && P.dtile_seg && P.status && P.flags && b->d_rgb && b->d_stride;
+         P.ptile_seg && P.tile_seg && P.dtile_seg && P.status && P.flags && P.counters && b->d_rgb && b->d_stride;
     if (ok && mode == ZJ_ALLOC_NONE) {
         // the rest of the range is this call's scratch
         const size_t used = align_up(b->plan_pool.off, 256);
@@ -779,8 +809,6 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     if (ok) {
         const int S = ZJ_MEM_SCRATCH;
         P.dtile_sum = dev_alloc<uint32_t>(b, (nbigd + 1) * 4, true, S);
-        P.tile_status = dev_alloc<uint64_t>(b, nbig + (b->segs.size() + 1) / 2 + 1, true, S);
-        P.seg_ticket = P.tile_status ? reinterpret_cast<uint32_t *>(P.tile_status + nbig) : nullptr;
         P.ust = dev_alloc<uint8_t>(b, ust_total + 1040, true, S);
         P.seg_payload_bits = dev_alloc<uint32_t>(b, b->segs.size(), true, S);
         P.seg_found = dev_alloc<uint32_t>(b, b->segs.size(), true, S);
@@ -791,7 +819,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
         P.dcabs = dev_alloc<int16_t>(b, nblk_total, true, S);
         P.dcbits = dev_alloc<uint8_t>(b, nblk_total, true, S);
         P.qcoef = dev_alloc<int16_t>(b, nblk_total * 64, false, S);
-        ok = P.dtile_sum && P.tile_status && P.ust && P.seg_payload_bits && P.seg_found && P.winfo && P.wbase && P.bitmap && P.blockpos && P.dcabs &&
+        ok = P.dtile_sum && P.ust && P.seg_payload_bits && P.seg_found && P.winfo && P.wbase && P.bitmap && P.blockpos && P.dcabs &&
              P.dcbits && P.qcoef;
     }
     P.rgb = b->d_rgb;
@@ -866,7 +894,8 @@ extern "C" int zj_workspace_estimate(const zj_image *images, size_t n, size_t *p
         plan += align_up((size_t)len, 16) + 16 + S * sizeof(ZjSegDev) + 4 * (chunks + B / 256 + (M / 128 + 1) + ptiles + utiles + dtiles) + 8 * (M / 16 + 2);
         plan += 2 * ZJ_SET_ENTRIES * 2 + ZJ_PSET_ENTRIES * 4 + 2 * ZJ_WT_ENTRIES * 4 + 512 + 4 * sizeof(ZjCanon) + 3 * 64 * 2;  // a table set (four forms) and quantisation tables of its own
         plan += sizeof(ZjMarkImg) + 8 * mtiles + 4 + 4 * (S + 1);           // restart-marker search
-        scr += 16 * dtiles + 8 * (utiles + S) + 2 * (len + 112 * S) + 8 * S + 8 * win + 7 * B + 128 * B;
+        plan += 8 * (utiles + S) + 64; // look-back words and tickets of the unstuff pass, cleared with the status words
+        scr += 16 * dtiles + 2 * (len + 112 * S) + 8 * S + 8 * win + 7 * B + 128 * B;
     }
     if (plan_bytes) *plan_bytes = (size_t)(plan + plan / 64);
     if (scratch_bytes) *scratch_bytes = (size_t)(scr + scr / 64);
@@ -951,9 +980,11 @@ static int decode_entropy(zj_batch *b)
         if (!hip_ok(c, hipStreamWaitEvent(st, b->ready, 0), "stream wait")) return ZJ_E_DEVICE;
         b->ready_waited = true;
     }
-    if (b->n && !hip_ok(c, hipMemsetAsync(b->P.status, 0, b->n * sizeof(uint32_t), st), "memset status")) return ZJ_E_DEVICE;
     b->entropy_launched = true;
-    if (b->L.nchunks == 0) return ZJ_OK;
+    if (b->L.nchunks == 0) { // nothing to decode: the status words are all this call has to clear (otherwise stage 1's one fill does)
+        if (b->n && !hip_ok(c, hipMemsetAsync(b->P.status, 0, b->n * sizeof(uint32_t), st), "memset status")) return ZJ_E_DEVICE;
+        return ZJ_OK;
+    }
     hipEvent_t *ev = nullptr;
     if (b->profiling) {
         if (!b->ev_valid) {
@@ -1071,7 +1102,7 @@ extern "C" int zj_batch_finish(zj_batch *b, uint32_t *status)
         b->pixels_pending = false;
     }
     if (b->decoded && b->L.nchunks) {
-        if (!hip_ok(c, hipMemcpy(b->h_flags, b->P.flags, 16, hipMemcpyDeviceToHost), "D2H flags")) return ZJ_E_DEVICE;
+        if (!hip_ok(c, hipMemcpy(b->h_flags, b->P.flags, 8, hipMemcpyDeviceToHost), "D2H flags")) return ZJ_E_DEVICE;
         if ((b->h_flags[0] || b->h_flags[1]) && b->range.on) {
             c->err = "part of a split stream: the walks did not converge, decode the stream whole";
             return ZJ_E_CHAIN;
@@ -1085,13 +1116,18 @@ extern "C" int zj_batch_finish(zj_batch *b, uint32_t *status)
                 zj_launch_stage1(b->P, b->L, st, nullptr);
                 if (!hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
             }
+            uint32_t passes = 0;
             for (uint32_t it = 0; it <= b->L.nchunks; it++) {
                 if (!hip_ok(c, hipMemsetAsync(b->P.flags, 0, 8, st), "memset flags")) return ZJ_E_DEVICE;
                 zj_launch_fix_only(b->P, b->L, st);
-                if (!hip_ok(c, hipMemcpyAsync(b->h_flags, b->P.flags, 16, hipMemcpyDeviceToHost, st), "D2H flags")) return ZJ_E_DEVICE;
+                passes++;
+                if (!hip_ok(c, hipMemcpyAsync(b->h_flags, b->P.flags, 8, hipMemcpyDeviceToHost, st), "D2H flags")) return ZJ_E_DEVICE;
                 if (!hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
                 if (!b->h_flags[0]) break;
             }
+            // the batch's later decode calls run that many fix passes up front (a pass that finds nothing to do is a few
+            // microseconds), so that a stream of this kind pays for the loop once
+            b->L.fix_iters = (int)std::min<uint32_t>(16u, std::max<uint32_t>((uint32_t)b->L.fix_iters, b->L.fix_iters + passes));
             if (!hip_ok(c, hipMemsetAsync(b->P.status, 0, b->n * sizeof(uint32_t), st), "memset status")) return ZJ_E_DEVICE;
             zj_launch_stage1_tail(b->P, b->L, st);
             bool any_rgb = false;
@@ -1100,7 +1136,7 @@ extern "C" int zj_batch_finish(zj_batch *b, uint32_t *status)
             if (!any_rgb) { L2.nstrips = 0; for (int c = 0; c < ZJ_K2_CLASSES; c++) L2.k2_count[c] = 0; }
             zj_launch_stage2(b->P, L2, st, nullptr);
             if (!hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
-            if (!hip_ok(c, hipMemcpy(b->h_flags, b->P.flags, 16, hipMemcpyDeviceToHost), "D2H flags")) return ZJ_E_DEVICE;
+            if (!hip_ok(c, hipMemcpy(b->h_flags, b->P.flags, 8, hipMemcpyDeviceToHost), "D2H flags")) return ZJ_E_DEVICE;
             if (b->h_flags[1]) { c->err = "subsequence records inconsistent after exhaustive fix-up"; return ZJ_E_DEVICE; }
         }
     }
@@ -1118,10 +1154,10 @@ extern "C" int zj_batch_counters(zj_batch *b, uint32_t *counters)
     zj_ctx *c = b->ctx;
     if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return ZJ_E_DEVICE;
     if (!hip_ok(c, hipStreamSynchronize(c->stream), "stream sync")) return ZJ_E_DEVICE;
-    uint32_t f[4] = {0, 0, 0, 0};
-    if (b->P.flags && !hip_ok(c, hipMemcpy(f, b->P.flags, 16, hipMemcpyDeviceToHost), "D2H flags")) return ZJ_E_DEVICE;
-    counters[0] = f[2];
-    counters[1] = f[3];
+    uint32_t f[2] = {0, 0};
+    if (b->P.counters && !hip_ok(c, hipMemcpy(f, b->P.counters, 8, hipMemcpyDeviceToHost), "D2H counters")) return ZJ_E_DEVICE;
+    counters[0] = f[0];
+    counters[1] = f[1];
     counters[2] = b->slow_path_calls;
     return ZJ_OK;
 }
@@ -1343,7 +1379,6 @@ extern "C" int zj_batch_range_front(zj_batch *b, zj_range_report *report)
     const ZjImgDev &d = b->imgs[0];
     const uint32_t bpm = d.bpm;
     memset(report, 0, sizeof *report);
-    if (!hip_ok(c, hipMemsetAsync(b->P.status, 0, sizeof(uint32_t), st), "memset status")) return ZJ_E_DEVICE;
     // the walks, and the block counts per window without a bias
     b->segs[0].blk_bias = 0;
     if (!hip_ok(c, hipMemcpyAsync(const_cast<ZjSegDev *>(b->P.segs), &b->segs[0], sizeof(ZjSegDev), hipMemcpyHostToDevice, st), "H2D segment")) return ZJ_E_DEVICE;
@@ -1352,8 +1387,19 @@ extern "C" int zj_batch_range_front(zj_batch *b, zj_range_report *report)
     uint32_t pay = 0, flags4[4] = {0, 0, 0, 0};
     if (!hip_ok(c, hipGetLastError(), "kernel launch") || !hip_ok(c, hipStreamSynchronize(st), "stream sync") ||
         !hip_ok(c, hipMemcpy(&pay, b->P.seg_payload_bits, 4, hipMemcpyDeviceToHost), "D2H payload") ||
-        !hip_ok(c, hipMemcpy(flags4, b->P.flags, 16, hipMemcpyDeviceToHost), "D2H flags")) return ZJ_E_DEVICE;
-    if (flags4[0]) { c->err = "part of a split stream: the walks did not converge, decode the stream whole"; return ZJ_E_CHAIN; }
+        !hip_ok(c, hipMemcpy(flags4, b->P.flags, 8, hipMemcpyDeviceToHost), "D2H flags")) return ZJ_E_DEVICE;
+    if (flags4[0]) {
+        // a fix lane ran through a whole chunk: iterate the fix pass to its fixed point, as zj_batch_finish does, and count again
+        for (uint32_t it = 0; flags4[0] && it <= b->L.nchunks; it++) {
+            if (!hip_ok(c, hipMemsetAsync(b->P.flags, 0, 8, st), "memset flags")) return ZJ_E_DEVICE;
+            zj_launch_fix_only(b->P, b->L, st);
+            if (!hip_ok(c, hipMemcpyAsync(flags4, b->P.flags, 8, hipMemcpyDeviceToHost, st), "D2H flags") || !hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
+            b->L.fix_iters = std::min(16, b->L.fix_iters + 1);
+        }
+        if (flags4[0]) { c->err = "part of a split stream: the walks did not converge, decode the stream whole"; return ZJ_E_CHAIN; }
+        zj_launch_range_dc(b->P, b->L, st); // the window counts again (the rest of it is repeated below, once the bias is known)
+        if (!hip_ok(c, hipGetLastError(), "kernel launch") || !hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
+    }
     ZjBoundary bx, by;
     if (!read_boundary(b, b->range.x_bits, pay, 0, &bx)) return ZJ_E_DEVICE;
     if (!bx.found) { c->err = "part of a split stream: no block begins behind its boundary"; return ZJ_E_CHAIN; }

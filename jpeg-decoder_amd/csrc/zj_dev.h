@@ -51,7 +51,9 @@ struct ZjParams {
     const uint32_t *strip_img;     // [stage-2 workgroup] index of its strip group inside its image
     const uint32_t *strip_img_img; // [stage-2 workgroup] image
     uint32_t *status;           // [image]
-    uint32_t *flags;            // [0] fix pass ran through a whole chunk, [1] record chain inconsistent
+    uint32_t *flags;            // [0] fix pass ran through a whole chunk, [1] record chain inconsistent; cleared by every decode call,
+                                // together with what lies behind them in one block: status words, look-back words, tickets
+    uint32_t *counters;         // the same two events counted over the batch's life
     uint8_t *const *rgb;        // [image] device pointers
     const size_t *rgb_stride;   // [image]
     uint32_t nchunks;
@@ -75,6 +77,7 @@ struct ZjLaunch {
     uint32_t npacked; // chunks shared by several short segments (the packed form of the sync kernel)
     uint32_t k2_first[ZJ_K2_CLASSES], k2_count[ZJ_K2_CLASSES]; // stage-2 workgroups per layout (2x2, 1x1, 2x1, 1x2, one component)
     int fix_iters;
+    size_t clear_bytes; // from ZjParams::flags on: what a decode call clears before its first kernel
 };
 
 // Restart-marker search over the uploaded scans (batch planning): one entry per image that has a restart interval.

@@ -348,20 +348,28 @@ void zj_build_walk_table(const uint16_t *tbl, bool isdc, uint16_t *wtbl)
 }
 
 // Pair entries: every first-level index is decoded symbol by symbol with the canonical description, as far
-// as the index bits determine whole codes.
-bool zj_build_pair_table(const ZjCanon *canon, bool isdc, uint32_t *ptbl)
+// as the index bits determine whole codes.  `partner` (DC tables only, may be null) is the AC table of the blocks
+// that use this DC table: the DC symbol of a block is always followed by the block's first AC symbol, so a DC
+// entry can hold that AC symbol as its second one when the DC code, its value bits and the AC code all lie inside
+// the index bits (a flat block -- DC difference 0, end of block -- is one lookup then).
+bool zj_build_pair_table(const ZjCanon *canon, bool isdc, uint32_t *ptbl, const ZjCanon *partner)
 {
     struct Code { uint32_t code, len, sym; };
-    std::vector<Code> codes;
+    std::vector<Code> codes, codes2;
     for (uint32_t l = 1; l <= 16; l++)
         for (uint32_t i = 0; i < canon->ncode[l]; i++)
             codes.push_back({(uint32_t)canon->mincode[l] + i, l, canon->symbols[(canon->valptr[l] + i) & 255u]});
+    if (isdc && partner)
+        for (uint32_t l = 1; l <= 16; l++)
+            for (uint32_t i = 0; i < partner->ncode[l]; i++)
+                codes2.push_back({(uint32_t)partner->mincode[l] + i, l, partner->symbols[(partner->valptr[l] + i) & 255u]});
     // the code that the top bits of the 32-bit window `x` begin with, among codes of at most `maxlen` bits
-    auto match = [&](uint32_t x, uint32_t maxlen) -> const Code * {
-        for (const Code &c : codes)
+    auto match_in = [](const std::vector<Code> &cs, uint32_t x, uint32_t maxlen) -> const Code * {
+        for (const Code &c : cs)
             if (c.len <= maxlen && (x >> (32u - c.len)) == c.code) return &c;
         return nullptr;
     };
+    auto match = [&](uint32_t x, uint32_t maxlen) { return match_in(codes, x, maxlen); };
     auto single = [&](const Code *c) { return zj_pair_single(zj_walk_entry(c ? ((c->len << 8) | c->sym) : 0u, isdc)); };
     const uint32_t invalid = single(nullptr);
     for (uint32_t i = 0; i < ZJ_PT_ENTRIES; i++) ptbl[i] = invalid;
@@ -371,8 +379,9 @@ bool zj_build_pair_table(const ZjCanon *canon, bool isdc, uint32_t *ptbl)
         if (!c1) continue; // no code, or the prefix of longer codes (entered below)
         uint32_t e = single(c1);
         const uint32_t t1 = e & 63u, a1 = (e >> 12) & 127u;
-        if (!isdc && a1 < 64u && t1 < (uint32_t)ZJ_PL1_BITS) {
-            const Code *c2 = match(x << t1, ZJ_PL1_BITS - t1);
+        const bool valid_dc = isdc && c1->sym <= 16u && !codes2.empty(); // a DC symbol above 16 is no symbol: the write pass reports it
+        if (((!isdc && a1 < 64u) || valid_dc) && t1 < (uint32_t)ZJ_PL1_BITS) {
+            const Code *c2 = match_in(isdc ? codes2 : codes, x << t1, ZJ_PL1_BITS - t1);
             if (c2) {
                 const uint32_t w2 = zj_walk_entry((c2->len << 8) | c2->sym, false);
                 const uint32_t t12 = t1 + (w2 & 63u), a12 = a1 + ((w2 >> 6) & 127u);

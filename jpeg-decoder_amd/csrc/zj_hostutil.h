@@ -17,7 +17,7 @@ void zj_build_walk_table(const uint16_t *tbl, bool isdc, uint16_t *wtbl);
 // The table in pair-entry form (zj_core.h): ZJ_PT_ENTRIES entries.  `canon` is the table's canonical
 // description from zj_build_table.  Returns false when the long codes do not fit the second level; the
 // first-level entries of long prefixes then send the walk to the canonical search.
-bool zj_build_pair_table(const ZjCanon *canon, bool isdc, uint32_t *ptbl);
+bool zj_build_pair_table(const ZjCanon *canon, bool isdc, uint32_t *ptbl, const ZjCanon *partner = nullptr);
 
 // The AC table in the direct form of its write entries (zj_core.h): ZJ_WT_ENTRIES entries and the form's parameter.
 // Returns false when the table's long codes do not fit; `wt` is then undefined.

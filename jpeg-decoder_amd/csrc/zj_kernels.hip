@@ -632,12 +632,12 @@ struct ZjEmitCol {
 
 __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t lut[ZJ_SET_ENTRIES];
+    __shared__ __attribute__((aligned(16))) uint32_t lut[ZJ_PSET_ENTRIES]; // pair entries, as in the sync pass
     __shared__ uint32_t bmp[ZJ_WIN_WORDS * 64];
     const uint32_t lane = threadIdx.x;
     const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
     const ZjImgDev im = P.imgs[P.segs[seg_first].img]; // by value: a reference would be read again after every store
-    load_lut_to_lds(lut, P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
+    load_ptab_to_lds(lut, P.ptabs + (size_t)im.lut_set * ZJ_PSET_ENTRIES);
     __syncthreads();
     if (lane >= 4u) return;
     const uint32_t chunk = blockIdx.x * 4u + lane;
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
 #pragma unroll
             for (int i = 0; i < ZJ_WIN_WORDS; i++) em.col[i * 64] = 0;
             em.wbase = w * ZJ_WIN_WORDS;
-            zj_decode_run<ZjBits, ZjEmitCol>(bits, lut, canon, selw, sel.bpm, st, wend < end ? wend : end, em);
+            zj_decode_run_pairs<ZjBits, ZjEmitCol>(bits, lut, canon, selw, sel.bpm, st, wend < end ? wend : end, em);
             uint32_t bw[ZJ_WIN_WORDS], n = 0;
 #pragma unroll
             for (int i = 0; i < ZJ_WIN_WORDS; i++) { bw[i] = em.col[i * 64]; n += __popc(bw[i]); }
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
         }
     }
     atomicOr(&P.flags[0], 1u); // ran through the whole chunk: the next one may have started from a stale state
-    atomicAdd(&P.flags[2], 1u);  // the same, counted over the batch's life (never cleared by a decode call)
+    atomicAdd(&P.counters[0], 1u); // the same, counted over the batch's life (never cleared by a decode call)
 }
 
 // ---------------------------------------------------------------------------------- k1s: scan
@@ -782,12 +782,13 @@ __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
         }
     } else {
         // few segments, possibly one long one (an image without restart markers): the pass is a chain of steps
-        // with the two barriers of the workgroup scan each, so a thread takes four consecutive windows per step
-        for (uint32_t t0 = 0; t0 < nwin; t0 += 1024u) {
-            const uint32_t w0 = t0 + threadIdx.x * 4u;
-            uint32_t n[4], sum = 0;
+        // with the two barriers of the workgroup scan each, so a thread takes eight consecutive windows per step
+        constexpr uint32_t PT = 8u; // windows per thread and step
+        for (uint32_t t0 = 0; t0 < nwin; t0 += 256u * PT) {
+            const uint32_t w0 = t0 + threadIdx.x * PT;
+            uint32_t n[PT], sum = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; j++) {
+            for (uint32_t j = 0; j < PT; j++) {
                 const uint32_t wi = w0 + j;
                 n[j] = 0;
                 if (wi < nwin) {
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
             uint32_t total;
             uint32_t run = carry + block_incl_scan<4>(sum, wsum, &total) - sum;
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; j++) {
+            for (uint32_t j = 0; j < PT; j++) {
                 if (w0 + j < nwin) wb[w0 + j] = run;
                 run += n[j];
             }
@@ -1421,7 +1422,7 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
                 if (p > cur.pay) st |= 4u;                                      // ZJ_ST_TRUNCATED
                 // a cleanly decoded block ends where the next one begins; if it does not, the position
                 // list does not describe the sequential decode
-                if (st == 0u && pnext != 0xFFFFFFFFu && pnext != p) { atomicOr(&P.flags[1], 1u); atomicAdd(&P.flags[3], 1u); }
+                if (st == 0u && pnext != 0xFFFFFFFFu && pnext != p) { atomicOr(&P.flags[1], 1u); atomicAdd(&P.counters[1], 1u); }
                 status |= st;
             }
             cur = nxt; nxt = nn;
@@ -2125,15 +2126,17 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
 {
     int e = 0;
     if (ev) hipEventRecord(ev[e++], st);
-    hipMemsetAsync(P.flags, 0, 8, st); // words 2 and 3 count over the batch's life
-    hipMemsetAsync(P.tile_status, 0, (size_t)L.ntiles * sizeof(uint64_t) + (size_t)L.nseg * sizeof(uint32_t), st); // look-back words and the tickets behind them
+    hipMemsetAsync(P.flags, 0, L.clear_bytes, st); // one fill: flags, status words, look-back words and the tickets behind them
     if (L.ntiles) hipLaunchKernelGGL((zj_k0_unstuff<128, 31, false>), dim3(L.ntiles), dim3(128), 0, st, P, 0u);
     if (L.nsmall) hipLaunchKernelGGL((zj_k0_unstuff<64, 15, true>), dim3(L.nsmall), dim3(64), 0, st, P, L.ntiles);
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1a_sync, dim3(L.nchunks / 4), dim3(256), 0, st, P);
     if (L.npacked) hipLaunchKernelGGL(zj_k1a_sync_packed, dim3(L.nchunks / 4), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
-    for (int i = 0; i < L.fix_iters; i++) hipLaunchKernelGGL(zj_k1b_fix, dim3(L.nchunks / 4), dim3(64), 0, st, P);
+    for (int i = 0; i < L.fix_iters; i++) {
+        if (i) hipMemsetAsync(P.flags, 0, 4, st); // only the last pass says whether the records have converged
+        hipLaunchKernelGGL(zj_k1b_fix, dim3(L.nchunks / 4), dim3(64), 0, st, P);
+    }
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
@@ -2150,13 +2153,15 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
 // to the DC values; the correction of the DC values and the coefficients.
 extern "C" void zj_launch_range_sync(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
 {
-    hipMemsetAsync(P.flags, 0, 8, st);
-    hipMemsetAsync(P.tile_status, 0, (size_t)L.ntiles * sizeof(uint64_t) + (size_t)L.nseg * sizeof(uint32_t), st);
+    hipMemsetAsync(P.flags, 0, L.clear_bytes, st);
     if (L.ntiles) hipLaunchKernelGGL((zj_k0_unstuff<128, 31, false>), dim3(L.ntiles), dim3(128), 0, st, P, 0u);
     if (L.nsmall) hipLaunchKernelGGL((zj_k0_unstuff<64, 15, true>), dim3(L.nsmall), dim3(64), 0, st, P, L.ntiles);
     hipLaunchKernelGGL(zj_k1a_sync, dim3(L.nchunks / 4), dim3(256), 0, st, P);
     if (L.npacked) hipLaunchKernelGGL(zj_k1a_sync_packed, dim3(L.nchunks / 4), dim3(256), 0, st, P);
-    for (int i = 0; i < L.fix_iters; i++) hipLaunchKernelGGL(zj_k1b_fix, dim3(L.nchunks / 4), dim3(64), 0, st, P);
+    for (int i = 0; i < L.fix_iters; i++) {
+        if (i) hipMemsetAsync(P.flags, 0, 4, st); // only the last pass says whether the records have converged
+        hipLaunchKernelGGL(zj_k1b_fix, dim3(L.nchunks / 4), dim3(64), 0, st, P);
+    }
     hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
 }
 

@@ -243,7 +243,10 @@ extern "C" int zjsim_pair_walk_check(const zj_huff *dc, const zj_huff *ac, uint3
     for (int t = 0; t < 4; t++) {
         if (!zj_build_table(t4[t], &tbl[t * ZJ_TBL_ENTRIES], &canon[t], l2_cap)) return -1;
         zj_build_walk_table(&tbl[t * ZJ_TBL_ENTRIES], t < 2, &wtbl[t * ZJ_TBL_ENTRIES]);
-        zj_build_pair_table(&canon[t], t < 2, &ptab[t * ZJ_PT_ENTRIES]);
+    }
+    for (int t = 0; t < 4; t++) {
+        // the DC tables carry the first AC symbol of their blocks as second symbol (selectors below: DC id k with AC id k)
+        zj_build_pair_table(&canon[t], t < 2, &ptab[t * ZJ_PT_ENTRIES], t < 2 ? &canon[2 + t] : nullptr);
         if (l2_cap == 0)
             for (uint32_t e = 0; e < (uint32_t)ZJ_PL1_SIZE; e++)
                 if (ptab[t * ZJ_PT_ENTRIES + e] & 0x80000000u) ptab[t * ZJ_PT_ENTRIES + e] = 0x80000000u;
@@ -282,7 +285,7 @@ extern "C" int zjsim_pair_walk_check(const zj_huff *dc, const zj_huff *ac, uint3
     }
     if (pairs_taken) {
         uint32_t n = 0;
-        for (uint32_t t = 2; t < 4; t++)
+        for (uint32_t t = 0; t < 4; t++)
             for (uint32_t e = 0; e < (uint32_t)ZJ_PL1_SIZE; e++) {
                 const uint32_t v = ptab[t * ZJ_PT_ENTRIES + e];
                 if (!(v & 0x80000000u) && ((v >> 6) & 63u) != (v & 63u)) n++;

@@ -55,7 +55,24 @@ struct zj_workspace {
     // context's: the next entropy pass on the shared scratch waits for it
     hipEvent_t pix_ev;
     bool pix_ev_valid, pix_pending;
+    // one live batch per plan slot; the workspace outlives its batches (a destroy while batches are alive is deferred to
+    // the last of them)
+    std::vector<zj_batch *> slot_batch;
+    uint32_t live;
+    bool dying;
+    // per slot: pinned staging for the output pointer and pitch tables of the slot's batch (grown on demand), and the
+    // event behind the copies that read them
+    struct SlotTables {
+        uint8_t **h_rgb;
+        size_t *h_stride;
+        uint32_t *h_flags;
+        size_t cap;
+        hipEvent_t copied;
+        bool ev_valid, ev_pending;
+    };
+    std::vector<SlotTables> tables;
 };
+static void workspace_free(zj_workspace *ws);
 
 struct zj_batch {
     zj_ctx *ctx;
@@ -74,6 +91,7 @@ struct zj_batch {
     bool plan_pooled, scratch_pooled;
     ZjPool plan_pool, scratch_pool;
     zj_workspace *ws;  // upload stream and staging of zj_batch_create_in, else NULL
+    uint32_t ws_slot;
     hipStream_t up;    // stream of the plan-time uploads and kernels
     hipEvent_t ready;  // recorded on the workspace's copy stream behind the uploads
     bool ready_valid, ready_waited;
@@ -314,7 +332,9 @@ extern "C" void zj_batch_destroy(zj_batch *b)
     if (b->pixels_pending) (void)hipEventSynchronize(b->pixels_done);
     if (b->ws) (void)hipStreamSynchronize(b->ws->copy_stream);
     for (void *p : b->allocs) (void)hipFree(p);
-    if (b->pinned) {
+    if (b->ws) {
+        // the tables belong to the workspace's slot
+    } else if (b->pinned) {
         if (b->h_rgb) (void)hipHostFree(b->h_rgb);
         if (b->h_stride) (void)hipHostFree(b->h_stride);
         if (b->h_flags) (void)hipHostFree(b->h_flags);
@@ -325,8 +345,17 @@ extern "C" void zj_batch_destroy(zj_batch *b)
         for (auto &e : b->ev) (void)hipEventDestroy(e);
     if (b->ready_valid) (void)hipEventDestroy(b->ready);
     if (b->split_ev_valid) { (void)hipEventDestroy(b->entropy_done); (void)hipEventDestroy(b->pixels_done); }
-    if (b->tables_ev_valid) (void)hipEventDestroy(b->tables_copied);
+    if (b->tables_ev_valid && !b->ws) (void)hipEventDestroy(b->tables_copied);
+    zj_workspace *ws = b->ws;
+    if (ws) {
+        if (b->ws_slot < ws->slot_batch.size() && ws->slot_batch[b->ws_slot] == b) {
+            ws->slot_batch[b->ws_slot] = nullptr;
+            ws->tables[b->ws_slot].ev_pending = b->tables_ev_pending;
+        }
+        if (ws->live) ws->live--;
+    }
     delete b;
+    if (ws && ws->dying && ws->live == 0) workspace_free(ws);
 }
 
 // Upload of the scans through the workspace's two pinned chunks: the raw arena is built chunk by chunk in
@@ -394,6 +423,9 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     memset(&b->scratch_pool, 0, sizeof b->scratch_pool);
     if (mode == ZJ_ALLOC_WORKSPACE) {
         b->ws = ws;
+        b->ws_slot = slot;
+        ws->live++; // from here on zj_batch_destroy gives the slot back
+        ws->slot_batch[slot] = b;
         b->up = ws->copy_stream;
         b->plan_pooled = b->scratch_pooled = true;
         b->plan_pool = ZjPool{ws->plan + (size_t)slot * ws->plan_bytes, ws->plan_bytes, 0};
@@ -833,6 +865,27 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
              hip_ok(ctx, hipHostMalloc((void **)&b->h_flags, 16, hipHostMallocDefault), "hipHostMalloc") &&
              hip_ok(ctx, hipEventCreateWithFlags(&b->tables_copied, hipEventDisableTiming), "hipEventCreate");
         b->tables_ev_valid = ok;
+    } else if (ok && b->ws) {
+        // pinned tables of the plan slot: the copies that read them are asynchronous, and the next decode call rewrites
+        // them only behind the slot's event
+        zj_workspace::SlotTables &t = ws->tables[slot];
+        if (t.ev_pending) { ok = hip_ok(ctx, hipEventSynchronize(t.copied), "event sync"); t.ev_pending = false; }
+        if (ok && t.cap < nn) {
+            if (t.h_rgb) (void)hipHostFree(t.h_rgb);
+            if (t.h_stride) (void)hipHostFree(t.h_stride);
+            t.h_rgb = nullptr; t.h_stride = nullptr; t.cap = 0;
+            const size_t cap = std::max<size_t>(nn, 256);
+            ok = hip_ok(ctx, hipHostMalloc((void **)&t.h_rgb, cap * sizeof(uint8_t *), hipHostMallocDefault), "hipHostMalloc") &&
+                 hip_ok(ctx, hipHostMalloc((void **)&t.h_stride, cap * sizeof(size_t), hipHostMallocDefault), "hipHostMalloc");
+            if (ok) t.cap = cap;
+        }
+        if (ok && !t.h_flags) ok = hip_ok(ctx, hipHostMalloc((void **)&t.h_flags, 16, hipHostMallocDefault), "hipHostMalloc");
+        if (ok && !t.ev_valid) { ok = hip_ok(ctx, hipEventCreateWithFlags(&t.copied, hipEventDisableTiming), "hipEventCreate"); t.ev_valid = ok; }
+        if (ok) {
+            b->h_rgb = t.h_rgb; b->h_stride = t.h_stride; b->h_flags = t.h_flags;
+            b->tables_copied = t.copied;
+            b->tables_ev_valid = true;
+        }
     } else if (ok) {
         b->h_rgb = (uint8_t **)calloc(nn, sizeof(uint8_t *));
         b->h_stride = (size_t *)calloc(nn, sizeof(size_t));
@@ -905,6 +958,12 @@ extern "C" int zj_workspace_estimate(const zj_image *images, size_t n, size_t *p
 extern "C" void zj_workspace_destroy(zj_workspace *ws)
 {
     if (!ws) return;
+    if (ws->live) { ws->dying = true; return; } // batches are still alive: the last of them frees the workspace
+    workspace_free(ws);
+}
+
+static void workspace_free(zj_workspace *ws)
+{
     (void)hipSetDevice(ws->ctx->device);
     if (ws->copy_stream) { (void)hipStreamSynchronize(ws->copy_stream); (void)hipStreamDestroy(ws->copy_stream); }
     (void)hipStreamSynchronize(ws->ctx->stream);
@@ -915,6 +974,12 @@ extern "C" void zj_workspace_destroy(zj_workspace *ws)
     for (int k = 0; k < 2; k++) {
         if (ws->stage[k]) (void)hipHostFree(ws->stage[k]);
         if (ws->stage_free[k]) (void)hipEventDestroy(ws->stage_free[k]);
+    }
+    for (auto &t : ws->tables) {
+        if (t.ev_valid) { if (t.ev_pending) (void)hipEventSynchronize(t.copied); (void)hipEventDestroy(t.copied); }
+        if (t.h_rgb) (void)hipHostFree(t.h_rgb);
+        if (t.h_stride) (void)hipHostFree(t.h_stride);
+        if (t.h_flags) (void)hipHostFree(t.h_flags);
     }
     if (ws->scratch) (void)hipFree(ws->scratch);
     if (ws->plan) (void)hipFree(ws->plan);
@@ -928,8 +993,14 @@ extern "C" zj_workspace *zj_workspace_create(zj_ctx *ctx, size_t scratch_bytes, 
     if (nslots == 0 || scratch_bytes == 0 || plan_bytes == 0) { ctx->err = "workspace sizes and slot count must be positive"; return nullptr; }
     if (!hip_ok(ctx, hipSetDevice(ctx->device), "hipSetDevice")) return nullptr;
     zj_workspace *ws = new zj_workspace();
-    memset(ws, 0, sizeof *ws);
     ws->ctx = ctx;
+    ws->scratch = nullptr; ws->plan = nullptr; ws->copy_stream = nullptr;
+    ws->stage[0] = ws->stage[1] = nullptr; ws->stage_free[0] = ws->stage_free[1] = nullptr;
+    ws->stage_used[0] = ws->stage_used[1] = false;
+    ws->pix_ev_valid = ws->pix_pending = false;
+    ws->live = 0; ws->dying = false;
+    ws->slot_batch.assign(nslots, nullptr);
+    ws->tables.assign(nslots, zj_workspace::SlotTables{nullptr, nullptr, nullptr, 0, nullptr, false, false});
     ws->scratch_bytes = align_up(scratch_bytes, 256);
     ws->plan_bytes = align_up(plan_bytes, 256);
     ws->nslots = nslots;
@@ -940,7 +1011,7 @@ extern "C" zj_workspace *zj_workspace_create(zj_ctx *ctx, size_t scratch_bytes, 
     for (int k = 0; ok && k < 2; k++)
         ok = hip_ok(ctx, hipHostMalloc((void **)&ws->stage[k], ws->stage_bytes, hipHostMallocDefault), "hipHostMalloc staging") &&
              hip_ok(ctx, hipEventCreateWithFlags(&ws->stage_free[k], hipEventDisableTiming), "hipEventCreate");
-    if (!ok) { zj_workspace_destroy(ws); return nullptr; }
+    if (!ok) { workspace_free(ws); return nullptr; }
     ctx->err_code = ZJ_OK;
     return ws;
 }
@@ -949,6 +1020,8 @@ extern "C" zj_batch *zj_batch_create_in(zj_workspace *ws, uint32_t slot, const z
 {
     if (!ws) return nullptr;
     if (slot >= ws->nslots) { ws->ctx->err = "no such plan slot"; ws->ctx->err_code = ZJ_E_INVALID; return nullptr; }
+    if (ws->dying) { ws->ctx->err = "the workspace is being destroyed"; ws->ctx->err_code = ZJ_E_INVALID; return nullptr; }
+    if (ws->slot_batch[slot]) { ws->ctx->err = "plan slot is still held by a live batch (destroy it first)"; ws->ctx->err_code = ZJ_E_INVALID; return nullptr; }
     return batch_create_impl(ws->ctx, images, n, flags, ZJ_ALLOC_WORKSPACE, ws, slot, nullptr, 0);
 }
 
@@ -1112,7 +1185,13 @@ extern "C" int zj_batch_finish(zj_batch *b, uint32_t *status)
             // fixed point (each pass completes at least one more chunk), then redo everything behind.
             b->slow_path_calls++;
             if (b->scratch_pooled) {
-                // another batch may have used the shared scratch since: start over from the stuffed scans
+                // another batch may have used the shared scratch since: start over from the stuffed scans -- behind the
+                // pixel pass of whichever batch of the workspace decoded last (it may still be reading the coefficients
+                // this rerun overwrites; its coefficients are gone afterwards, as after any decode call on the workspace)
+                if (b->ws && b->ws->pix_pending) {
+                    if (!hip_ok(c, hipStreamWaitEvent(st, b->ws->pix_ev, 0), "stream wait")) return ZJ_E_DEVICE;
+                    b->ws->pix_pending = false;
+                }
                 zj_launch_stage1(b->P, b->L, st, nullptr);
                 if (!hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
             }
@@ -1188,6 +1267,22 @@ extern "C" int zj_batch_export_coef(zj_batch *b, size_t i, int16_t *qcoef, int16
         if (!ok) return ZJ_E_DEVICE;
     }
     if (!hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
+    // coefficients are produced for the MCUs [mcu_lo, mcu_hi) only (all of them unless the batch was made with a window of
+    // rows or is a part of a split stream): what the arena holds elsewhere is not this image's, so the export is zero there
+    const ZjImgDev &d = b->imgs[i];
+    const size_t lo = (size_t)d.mcu_lo * d.bpm * 128u, hi = std::min(bytes, (size_t)d.mcu_hi * d.bpm * 128u);
+    for (int16_t *dst : {qcoef, dqcoef}) {
+        if (!dst) continue;
+        uint8_t *p8 = reinterpret_cast<uint8_t *>(dst);
+        if (mem == ZJ_MEM_DEVICE) {
+            if (lo && !hip_ok(c, hipMemsetAsync(p8, 0, std::min(lo, bytes), st), "memset")) return ZJ_E_DEVICE;
+            if (hi < bytes && !hip_ok(c, hipMemsetAsync(p8 + hi, 0, bytes - hi, st), "memset")) return ZJ_E_DEVICE;
+        } else {
+            if (lo) memset(p8, 0, std::min(lo, bytes));
+            if (hi < bytes) memset(p8 + hi, 0, bytes - hi);
+        }
+    }
+    if (mem == ZJ_MEM_DEVICE && !hip_ok(c, hipStreamSynchronize(st), "stream sync")) return ZJ_E_DEVICE;
     return ZJ_OK;
 }
 

@@ -168,6 +168,9 @@ def test_rows_of_images_without_restart_markers(ctx):
                 q = b.coefficients(0)
                 lo, hi = r0 * mcux * bpm, (r0 + n) * mcux * bpm
                 assert np.array_equal(q[lo:hi], ref.qcoef[lo:hi]), (name, world, r0)
+                assert not q[:lo].any() and not q[hi:].any()  # outside the window nothing was produced: exported as zeros
+                dq = b.coefficients(0, dequantised=True)
+                assert np.array_equal(dq[lo:hi], ref.dqcoef[lo:hi]) and not dq[:lo].any() and not dq[hi:].any()
                 b.close()
             assert np.array_equal(np.concatenate(got, 0), ref.rgb), (name, world)
         with pytest.raises(J.DecodeError):

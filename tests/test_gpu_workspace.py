@@ -147,6 +147,53 @@ def test_two_decodes_in_flight_with_different_outputs(ctx):
     b.close()
 
 
+def test_two_decodes_in_flight_on_a_workspace_batch(ctx):
+    """The same for a batch that lives in a workspace: its pointer tables are staged in pinned memory of the plan slot and
+    rewritten only behind the event of the copies that read them."""
+    files = [synth.encode(1920, 1080, 2, 2, 90, 0, 250 + k, 0) for k in range(4)]
+    imgs = [J.ParsedImage(f) for f in files]
+    plan, scratch = J.Workspace.estimate(imgs)
+    ws = J.Workspace(ctx, scratch, plan, 1)
+    b = J.Batch(ctx, imgs, workspace=ws, slot=0)
+    a, c = b.alloc_rgb(), b.alloc_rgb()
+    for o in a + c:
+        o.fill_(0x77)
+    for _ in range(4):
+        b.decode(a)
+    b.decode(c)
+    b.decode(a)
+    st = b.finish()
+    _check(files, imgs, a, st)
+    _check(files, imgs, c, st)
+    b.close()
+    ws.close()
+
+
+def test_plan_slots_and_workspace_lifetime(ctx):
+    """A plan slot holds one live batch: a second zj_batch_create_in on it is refused until the first is destroyed (it
+    would overwrite scans and tables a queued decode still reads).  A workspace destroyed while batches are alive is
+    freed by the last of them, so closing in the wrong order is safe."""
+    files = [synth.encode(320, 240, 2, 2, 90, 0, 260 + k, 0) for k in range(2)]
+    imgs = [J.ParsedImage(f) for f in files]
+    plan, scratch = J.Workspace.estimate(imgs)
+    ws = J.Workspace(ctx, scratch, plan, 2)
+    b0 = J.Batch(ctx, imgs, workspace=ws, slot=0)
+    with pytest.raises(J.DecodeError, match="still held"):
+        J.Batch(ctx, imgs, workspace=ws, slot=0)
+    b1 = J.Batch(ctx, imgs[:1], workspace=ws, slot=1)
+    b0.close()
+    b0 = J.Batch(ctx, imgs, workspace=ws, slot=0)  # the slot is free again
+    outs = b0.alloc_rgb()
+    b0.decode(outs)
+    ws.close()  # before its batches: deferred
+    with pytest.raises(J.DecodeError):
+        J.Batch(ctx, imgs, workspace=ws, slot=0)  # a closed workspace takes no new batches
+    st = b0.finish()
+    _check(files, imgs, outs, st)
+    b1.close()
+    b0.close()  # the last batch frees the workspace
+
+
 def test_decode_rejects_bad_output_geometry(ctx):
     import torch
     im = J.ParsedImage(synth.encode(100, 40, 2, 2, 90, 0, 240, 0))

@@ -40,9 +40,12 @@ def _noalloc_entry_point(ctx, imgs, shapes):
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
     strides = (C.c_size_t * n)(*[t.stride(0) for t in outs])
     st = (C.c_uint32 * n)()
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(0)[0]
     rc = B.lib().zj_decode_batch_noalloc(ctx.h, arr, n, ptrs, strides, st)
     assert rc == 0, ctx.last_error()
     torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(0)[0] == free_before  # the call took no device memory (and gave none back)
     return outs, np.array(st[:], np.uint32)
 
 

@@ -37,6 +37,10 @@ pub struct Decoder {
     reader: BufReader<File>,
     w: u16,
     h: u16,
+    /// The GPU context, created on the first `decode()` and kept for the decoder's life: creating one costs far more
+    /// than a decode (stream, first-use initialisation of the runtime), so a caller that decodes file after file reuses
+    /// a `Decoder` -- see `reset()` -- or hands one `Gpu` to many decoders with `with_gpu()`.
+    gpu: Option<std::rc::Rc<Gpu>>,
 }
 
 fn be16(b: &[u8], at: usize) -> Result<usize, DecodeError> {
@@ -46,7 +50,27 @@ fn be16(b: &[u8], at: usize) -> Result<usize, DecodeError> {
 
 impl Decoder {
     pub fn new(file: File) -> Self {
-        Decoder { reader: BufReader::new(file), w: 0, h: 0 }
+        Decoder { reader: BufReader::new(file), w: 0, h: 0, gpu: None }
+    }
+
+    /// A decoder that shares an existing GPU context (one per GPU and thread).
+    pub fn with_gpu(file: File, gpu: std::rc::Rc<Gpu>) -> Self {
+        Decoder { reader: BufReader::new(file), w: 0, h: 0, gpu: Some(gpu) }
+    }
+
+    /// Point the decoder at another file, keeping its GPU context.
+    pub fn reset(&mut self, file: File) {
+        self.reader = BufReader::new(file);
+        self.w = 0;
+        self.h = 0;
+    }
+
+    fn gpu(&mut self) -> Result<std::rc::Rc<Gpu>, DecodeError> {
+        if self.gpu.is_none() {
+            let g = Gpu::new(0).ok_or_else(|| DecodeError::Device(ZJ_E_DEVICE, "no usable GPU".into()))?;
+            self.gpu = Some(std::rc::Rc::new(g));
+        }
+        Ok(self.gpu.as_ref().unwrap().clone())
     }
 
     pub fn decode(&mut self) -> Result<(), DecodeError> {
@@ -138,7 +162,7 @@ impl Decoder {
                     };
                     let mut buf = vec![0u8; 3 * self.w as usize * self.h as usize];
                     let out = ZjOutput { rgb: buf.as_mut_ptr(), rgb_stride: 0, qcoef: core::ptr::null_mut(), dqcoef: core::ptr::null_mut(), mem: ZJ_MEM_HOST };
-                    let gpu = Gpu::new(0).ok_or_else(|| DecodeError::Device(ZJ_E_DEVICE, "no usable GPU".into()))?;
+                    let gpu = self.gpu()?; // created once, kept in the decoder
                     let mut status = 0u32;
                     let rc = unsafe { zj_decode_batch(gpu.raw(), &img, 1, &out, &mut status) };
                     if rc != ZJ_OK { return Err(DecodeError::Device(rc, gpu.last_error())); }

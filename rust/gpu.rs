@@ -15,6 +15,7 @@ pub const ZJ_E_UNSUPPORTED: c_int = -3;
 pub const ZJ_E_DEVICE: c_int = -4;
 pub const ZJ_E_NOMEM: c_int = -5;
 pub const ZJ_E_IO: c_int = -6;
+pub const ZJ_E_CHAIN: c_int = -7;
 
 pub const ZJ_ST_BAD_CODE: u32 = 1;
 pub const ZJ_ST_COEF_OVERFLOW: u32 = 2;
@@ -60,6 +61,20 @@ pub struct ZjOutput {
     pub mem: c_int,
 }
 
+/// What a part of a stream that is split over several GPUs tells the other parts (all-gathered by the caller).
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct ZjRangeReport {
+    pub start_delta: i32,
+    pub start_k: u32,
+    pub end_delta: i32,
+    pub end_k: u32,
+    pub mcus: u32,
+    pub dc_sum: [i16; 3],
+    pub reserved: u16,
+    pub reserved2: u32,
+}
+
 pub enum ZjCtx {}
 pub enum ZjBatch {}
 pub enum ZjWorkspace {}
@@ -94,6 +109,15 @@ extern "C" {
     pub fn zj_workspace_destroy(ws: *mut ZjWorkspace);
     pub fn zj_batch_create_in(ws: *mut ZjWorkspace, slot: u32, imgs: *const ZjImage, n: usize, flags: u32) -> *mut ZjBatch;
     pub fn zj_batch_create_rows(ctx: *mut ZjCtx, imgs: *const ZjImage, n: usize, flags: u32, row0: *const u32, nrows: *const u32) -> *mut ZjBatch;
+
+    // One image without restart markers over several GPUs, entropy front included: plan, front (fills this part's report),
+    // all-gather of the reports by the caller, resolve (ZJ_E_CHAIN: the parts do not join up, use zj_batch_create_rows),
+    // decode into the MCU rows [row0, row0 + nrows), zj_batch_finish.
+    pub fn zj_batch_create_range(ctx: *mut ZjCtx, img: *const ZjImage, rank: u32, nranks: u32, lead_bytes: u32, flags: u32) -> *mut ZjBatch;
+    pub fn zj_batch_range_front(b: *mut ZjBatch, report: *mut ZjRangeReport) -> c_int;
+    pub fn zj_batch_range_resolve(b: *mut ZjBatch, all: *const ZjRangeReport, nranks: u32, mcu_first: *mut u32, mcu_count: *mut u32,
+                                  row0: *mut u32, nrows: *mut u32) -> c_int;
+    pub fn zj_batch_range_decode(b: *mut ZjBatch, rgb: *mut u8, stride: usize) -> c_int;
 
     // One restart-marked image cut into bands (one per GPU).
     pub fn zj_restart_offsets(img: *const ZjImage, offsets: *mut usize, cap: usize) -> usize;

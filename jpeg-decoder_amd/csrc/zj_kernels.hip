@@ -630,14 +630,20 @@ struct ZjEmitCol {
     }
 };
 
+// PAIRS: walk with pair entries (up to two symbols a lookup, 20 KB of tables per workgroup) or with walk entries (one
+// symbol, 6 KB).  A few long walks -- one image, whose fix lanes are a serial tail of the sync pass -- gain from the
+// pairs; a large batch has thousands of workgroups whose table loads are most of the pass, and takes the small tables.
+template <bool PAIRS>
 __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lut[ZJ_PSET_ENTRIES]; // pair entries, as in the sync pass
+    typedef typename std::conditional<PAIRS, uint32_t, uint16_t>::type entry_t;
+    __shared__ __attribute__((aligned(16))) entry_t lut[PAIRS ? ZJ_PSET_ENTRIES : ZJ_SET_ENTRIES];
     __shared__ uint32_t bmp[ZJ_WIN_WORDS * 64];
     const uint32_t lane = threadIdx.x;
     const uint32_t seg_first = P.chunk_seg[blockIdx.x * 4u];
     const ZjImgDev im = P.imgs[P.segs[seg_first].img]; // by value: a reference would be read again after every store
-    load_ptab_to_lds(lut, P.ptabs + (size_t)im.lut_set * ZJ_PSET_ENTRIES);
+    if constexpr (PAIRS) load_ptab_to_lds(reinterpret_cast<uint32_t *>(lut), P.ptabs + (size_t)im.lut_set * ZJ_PSET_ENTRIES);
+    else load_lut_to_lds(reinterpret_cast<uint16_t *>(lut), P.wluts + (size_t)im.lut_set * ZJ_SET_ENTRIES);
     __syncthreads();
     if (lane >= 4u) return;
     const uint32_t chunk = blockIdx.x * 4u + lane;
@@ -671,7 +677,8 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
 #pragma unroll
             for (int i = 0; i < ZJ_WIN_WORDS; i++) em.col[i * 64] = 0;
             em.wbase = w * ZJ_WIN_WORDS;
-            zj_decode_run_pairs<ZjBits, ZjEmitCol>(bits, lut, canon, selw, sel.bpm, st, wend < end ? wend : end, em);
+            if constexpr (PAIRS) zj_decode_run_pairs<ZjBits, ZjEmitCol>(bits, reinterpret_cast<const uint32_t *>(lut), canon, selw, sel.bpm, st, wend < end ? wend : end, em);
+            else zj_decode_run<ZjBits, ZjEmitCol>(bits, reinterpret_cast<const uint16_t *>(lut), canon, selw, sel.bpm, st, wend < end ? wend : end, em);
             uint32_t bw[ZJ_WIN_WORDS], n = 0;
 #pragma unroll
             for (int i = 0; i < ZJ_WIN_WORDS; i++) { bw[i] = em.col[i * 64]; n += __popc(bw[i]); }
@@ -2112,6 +2119,12 @@ __global__ __launch_bounds__(256) void zj_kx_dequant(ZjParams P, uint32_t ii, in
 }
 
 // ---------------------------------------------------------------------------------- launchers
+static void zj_launch_fix(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
+{
+    if (L.nchunks / 4 <= 1024u) hipLaunchKernelGGL(zj_k1b_fix<true>, dim3(L.nchunks / 4), dim3(64), 0, st, P);
+    else hipLaunchKernelGGL(zj_k1b_fix<false>, dim3(L.nchunks / 4), dim3(64), 0, st, P);
+}
+
 static void zj_launch_dcscan(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
 {
     if (L.ndmulti) { // segments of more than one tile: their tile sums first
@@ -2135,7 +2148,7 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     if (ev) hipEventRecord(ev[e++], st);
     for (int i = 0; i < L.fix_iters; i++) {
         if (i) hipMemsetAsync(P.flags, 0, 4, st); // only the last pass says whether the records have converged
-        hipLaunchKernelGGL(zj_k1b_fix, dim3(L.nchunks / 4), dim3(64), 0, st, P);
+        zj_launch_fix(P, L, st);
     }
     if (ev) hipEventRecord(ev[e++], st);
     hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
@@ -2160,7 +2173,7 @@ extern "C" void zj_launch_range_sync(const ZjParams &P, const ZjLaunch &L, hipSt
     if (L.npacked) hipLaunchKernelGGL(zj_k1a_sync_packed, dim3(L.nchunks / 4), dim3(256), 0, st, P);
     for (int i = 0; i < L.fix_iters; i++) {
         if (i) hipMemsetAsync(P.flags, 0, 4, st); // only the last pass says whether the records have converged
-        hipLaunchKernelGGL(zj_k1b_fix, dim3(L.nchunks / 4), dim3(64), 0, st, P);
+        zj_launch_fix(P, L, st);
     }
     hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
 }
@@ -2189,7 +2202,7 @@ extern "C" void zj_launch_markers(const ZjMarkParams &M, hipStream_t st)
 
 extern "C" void zj_launch_fix_only(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
 {
-    hipLaunchKernelGGL(zj_k1b_fix, dim3(L.nchunks / 4), dim3(64), 0, st, P);
+    zj_launch_fix(P, L, st);
 }
 
 extern "C" void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipStream_t st)

@@ -1630,7 +1630,9 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
     // the few descriptor fields of the loop, read once (through the reference they would be read again,
     // and waited for, after every store)
     const uint32_t im_first_block = im.first_block, im_h = im.h, im_mcux = im.mcux, im_strips_x = im.strips_x, im_w = im.w, im_row0 = im.row0;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // the wavefront's index as a scalar: what depends on it (the tile's place in the image, its coefficients' address, its
+    // share of LDS) is then worked out by the scalar unit instead of once per lane
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     float *blk = blk_all + wave * (WB * ZJ_K2_BSTRIDE);
     uint8_t *rgb = P.rgb[ii];
     if (rgb == nullptr) return;

@@ -232,7 +232,8 @@ def test_stream_without_restart_markers_split_into_parts(ctx):
     rows, or nothing at all."""
     cases = [(fixture_bytes("large.jpg"), (2, 3, 8), 16384), (fixture_bytes("porsche.jpg"), (2, 5), 4096),
              (synth.encode(1000, 600, 2, 2, 90, 0, 91, 0), (2, 4, 7), 8192), (synth.encode(640, 480, 2, 1, 85, 2, 92, 0), (3,), 8192),
-             (synth.encode(333, 211, 0, 0, 90, 0, 93, 0), (2,), 2048)]
+             (synth.encode(333, 211, 0, 0, 90, 0, 93, 0), (2,), 2048),
+             (synth.encode(64, 48, 2, 2, 90, 0, 94, 0), (1, 8), 4096), (synth.encode(8, 8, 1, 1, 90, 0, 95, 0), (3,), 64)]
     for data, counts, lead in cases:
         ref = oracle.decode(data)
         scan_len = oracle.probe(data).scan_len

@@ -43,11 +43,13 @@
 // The sync pass, which walks every symbol of every stream once without producing coefficients, uses a third
 // form with up to two symbols per lookup ("pair entries"): ZJ_PT_ENTRIES uint32 entries per table, a first
 // level indexed by the next ZJ_PL1_BITS bits followed by second-level sub-tables for longer codes.
-//   entry, bit 31 clear:  [5:0]   t1   bits of the first symbol, code and value (1..32)
-//                         [11:6]  t12  bits of both symbols (= t1 when the entry holds one symbol)
-//                         [18:12] a1   zig-zag advance of the first symbol (as in a walk entry)
-//                         [25:19] a12  advance of both (= a1 when the entry holds one symbol; a second symbol
-//                                      that is an EOB adds 64)
+//   entry, bit 31 clear:  byte 0  t1   bits of the first symbol, code and value (1..32)
+//                         byte 1  t12  bits of both symbols (= t1 when the entry holds one symbol)
+//                         byte 2  a1   zig-zag advance of the first symbol (as in a walk entry)
+//                         byte 3  a12  advance of both (= a1 when the entry holds one symbol; a second symbol
+//                                      that is an EOB adds 64; at most 127, so bit 31 stays clear)
+//                         Whole bytes, so that the kernels' arithmetic picks the fields up as operands (SDWA byte
+//                         selects) instead of extracting them first.
 //   entry, bit 31 set  :  first level only: [26:24] nb = extra index bits (1..6), [8:0] offset of the sub-table
 //                         inside the second level; nb == 0: use the canonical search.
 // A second symbol is entered only behind an AC symbol that is no EOB, and only when its whole code lies inside
@@ -538,7 +540,7 @@ ZJ_HD void zj_decode_run(BITS &bits, const uint16_t *wlut, const ZjCanon *canon,
 ZJ_HD uint32_t zj_pair_single(uint32_t walk_entry)
 {
     const uint32_t tot = walk_entry & 63u, adv = (walk_entry >> 6) & 127u;
-    return tot | (tot << 6) | (adv << 12) | (adv << 19);
+    return tot | (tot << 8) | (adv << 16) | (adv << 24);
 }
 
 // First-level pair entry for the next bits of the stream (LDS = true: the table is in LDS, kernels only).
@@ -582,11 +584,11 @@ ZJ_HD void zj_decode_run_pairs(BITS &bits, const uint32_t *ptab, const ZjCanon *
         const bool isdc = (z == 0);
         const uint32_t t = (selw >> (2u * b + (isdc ? 0u : 16u))) & 3u;
         const uint32_t e = zj_lookup_pair<CANON, LDS>(ptab + t * ZJ_PT_ENTRIES, canon ? canon + t : nullptr, top, t < 2u);
-        const uint32_t t1 = e & 63u, a1 = (e >> 12) & 127u;
+        const uint32_t t1 = e & 255u, a1 = (e >> 16) & 255u;
         const uint32_t z1 = z + a1;
         const bool one = z1 >= 64u || p + t1 >= stop;
-        const uint32_t tot = one ? t1 : ((e >> 6) & 63u);
-        const uint32_t z2 = one ? z1 : z + ((e >> 19) & 127u);
+        const uint32_t tot = one ? t1 : ((e >> 8) & 255u);
+        const uint32_t z2 = one ? z1 : z + (e >> 24);
         em.block_start(p, isdc ? 1u : 0u);
         const bool endblk = z2 >= 64u;
         z = endblk ? 0u : z2;

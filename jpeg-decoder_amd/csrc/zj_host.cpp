@@ -378,14 +378,14 @@ bool zj_build_pair_table(const ZjCanon *canon, bool isdc, uint32_t *ptbl, const 
         const Code *c1 = match(x, ZJ_PL1_BITS);
         if (!c1) continue; // no code, or the prefix of longer codes (entered below)
         uint32_t e = single(c1);
-        const uint32_t t1 = e & 63u, a1 = (e >> 12) & 127u;
+        const uint32_t t1 = e & 255u, a1 = (e >> 16) & 255u;
         const bool valid_dc = isdc && c1->sym <= 16u && !codes2.empty(); // a DC symbol above 16 is no symbol: the write pass reports it
         if (((!isdc && a1 < 64u) || valid_dc) && t1 < (uint32_t)ZJ_PL1_BITS) {
             const Code *c2 = match_in(isdc ? codes2 : codes, x << t1, ZJ_PL1_BITS - t1);
             if (c2) {
                 const uint32_t w2 = zj_walk_entry((c2->len << 8) | c2->sym, false);
                 const uint32_t t12 = t1 + (w2 & 63u), a12 = a1 + ((w2 >> 6) & 127u);
-                if (t12 <= 32u) e = t1 | (t12 << 6) | (a1 << 12) | (a12 << 19);
+                if (t12 <= 32u && a12 < 128u) e = t1 | (t12 << 8) | (a1 << 16) | (a12 << 24);
             }
         }
         ptbl[idx] = e;

@@ -288,7 +288,7 @@ extern "C" int zjsim_pair_walk_check(const zj_huff *dc, const zj_huff *ac, uint3
         for (uint32_t t = 0; t < 4; t++)
             for (uint32_t e = 0; e < (uint32_t)ZJ_PL1_SIZE; e++) {
                 const uint32_t v = ptab[t * ZJ_PT_ENTRIES + e];
-                if (!(v & 0x80000000u) && ((v >> 6) & 63u) != (v & 63u)) n++;
+                if (!(v & 0x80000000u) && ((v >> 8) & 255u) != (v & 255u)) n++;
             }
         *pairs_taken = n;
     }

@@ -700,7 +700,7 @@ __global__ __launch_bounds__(64) void zj_k1b_fix(ZjParams P)
 
 // ---------------------------------------------------------------------------------- k1s: scan
 // One workgroup per segment, windows in stream order: wbase[w] = number of blocks that begin before
-// window w.
+// window w.  This form is for batches with enough segments (256 or more) to fill the GPU.
 __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
 {
     __shared__ uint32_t wsum[8];
@@ -712,8 +712,8 @@ __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
     const uint32_t *rec = P.winfo + sg.first_win;
     uint32_t *wb = P.wbase + sg.first_win;
     uint32_t carry = sg.blk_bias;
-    if (P.nseg >= 256u && sg.lanes == 64u && sg.nsub <= 128u) {
-        // Enough segments to fill the GPU, and one or two whole chunks of 64 subsequences (a longer segment is a longer
+    if (sg.lanes == 64u && sg.nsub <= 128u) {
+        // One or two whole chunks of 64 subsequences (a longer segment is a longer
         // chain of tiles than of the plain steps below): the records lie [chunk][window of
         // the subsequence][lane] while the result goes out in stream order [lane][window], so a chunk is taken in
         // tiles of 64 windows x 64 lanes through LDS, with the reads and the writes both along their own layout.
@@ -773,8 +773,8 @@ __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
             }
             carry += chunk_total;
         }
-    } else if (P.nseg >= 256u) {
-        // enough segments to fill the GPU: one window per thread and step, neighbouring threads read neighbouring records
+    } else {
+        // one window per thread and step, neighbouring threads read neighbouring records
         for (uint32_t t0 = 0; t0 < nwin; t0 += 256u) {
             const uint32_t wi = t0 + threadIdx.x;
             uint32_t n = 0;
@@ -787,32 +787,43 @@ __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
             if (wi < nwin) wb[wi] = carry + inc - n;
             carry += total;
         }
-    } else {
-        // few segments, possibly one long one (an image without restart markers): the pass is a chain of steps
-        // with the two barriers of the workgroup scan each, so a thread takes eight consecutive windows per step
-        constexpr uint32_t PT = 8u; // windows per thread and step
-        for (uint32_t t0 = 0; t0 < nwin; t0 += 256u * PT) {
-            const uint32_t w0 = t0 + threadIdx.x * PT;
-            uint32_t n[PT], sum = 0;
+    }
+    if (threadIdx.x == 0) P.seg_found[s] = carry;
+}
+
+// The same for a batch of few segments, possibly one long one (an image without restart markers): the pass is a chain of
+// steps with the two barriers of the workgroup scan each, so the workgroup is as large as it can be and a thread takes
+// eight consecutive windows per step.
+__global__ __launch_bounds__(1024) void zj_k1s_scan_few(ZjParams P)
+{
+    __shared__ uint32_t wsum[17];
+    const uint32_t s = blockIdx.x;
+    const ZjSegDev sg = P.segs[s];
+    const uint32_t NC = sg.nc;
+    const uint32_t pay = P.seg_payload_bits[s];
+    const uint32_t nwin = min(sg.nsub * NC, (pay + ZJ_WIN_BITS - 1u) / ZJ_WIN_BITS);
+    const uint32_t *rec = P.winfo + sg.first_win;
+    uint32_t *wb = P.wbase + sg.first_win;
+    uint32_t carry = sg.blk_bias;
+    constexpr uint32_t PT = 8u; // windows per thread and step
+    for (uint32_t t0 = 0; t0 < nwin; t0 += 1024u * PT) {
+        const uint32_t w0 = t0 + threadIdx.x * PT;
+        uint32_t n[PT], sum = 0;
+        uint32_t q = w0 / NC, c = w0 - q * NC;
 #pragma unroll
-            for (uint32_t j = 0; j < PT; j++) {
-                const uint32_t wi = w0 + j;
-                n[j] = 0;
-                if (wi < nwin) {
-                    const uint32_t q = wi / NC, c = wi - q * NC;
-                    n[j] = rec[zj_rec_index(q, c, NC, sg.lanes)] >> 16;
-                }
-                sum += n[j];
-            }
-            uint32_t total;
-            uint32_t run = carry + block_incl_scan<4>(sum, wsum, &total) - sum;
-#pragma unroll
-            for (uint32_t j = 0; j < PT; j++) {
-                if (w0 + j < nwin) wb[w0 + j] = run;
-                run += n[j];
-            }
-            carry += total;
+        for (uint32_t j = 0; j < PT; j++) {
+            n[j] = (w0 + j < nwin) ? rec[zj_rec_index(q, c, NC, sg.lanes)] >> 16 : 0u;
+            sum += n[j];
+            if (++c == NC) { c = 0; q++; }
         }
+        uint32_t total;
+        uint32_t run = carry + block_incl_scan<16>(sum, wsum, &total) - sum;
+#pragma unroll
+        for (uint32_t j = 0; j < PT; j++) {
+            if (w0 + j < nwin) wb[w0 + j] = run;
+            run += n[j];
+        }
+        carry += total;
     }
     if (threadIdx.x == 0) P.seg_found[s] = carry;
 }
@@ -2127,6 +2138,12 @@ static void zj_launch_fix(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
     else hipLaunchKernelGGL(zj_k1b_fix<false>, dim3(L.nchunks / 4), dim3(64), 0, st, P);
 }
 
+static void zj_launch_scan(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
+{
+    if (L.nseg >= 256u) hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL(zj_k1s_scan_few, dim3(L.nseg), dim3(1024), 0, st, P);
+}
+
 static void zj_launch_dcscan(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
 {
     if (L.ndmulti) { // segments of more than one tile: their tile sums first
@@ -2153,7 +2170,7 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
         zj_launch_fix(P, L, st);
     }
     if (ev) hipEventRecord(ev[e++], st);
-    hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
+    zj_launch_scan(P, L, st);
     if (ev) hipEventRecord(ev[e++], st);
     if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
@@ -2177,12 +2194,12 @@ extern "C" void zj_launch_range_sync(const ZjParams &P, const ZjLaunch &L, hipSt
         if (i) hipMemsetAsync(P.flags, 0, 4, st); // only the last pass says whether the records have converged
         zj_launch_fix(P, L, st);
     }
-    hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
+    zj_launch_scan(P, L, st);
 }
 
 extern "C" void zj_launch_range_dc(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
 {
-    hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P); // again, from the segment's bias
+    zj_launch_scan(P, L, st); // again, from the segment's bias
     if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1c_dcdiff, dim3((L.nblk256 + ZJ_K1C_NB - 1) / ZJ_K1C_NB), dim3(256), 0, st, P, L.nblk256);
     zj_launch_dcscan(P, L, st);
@@ -2209,7 +2226,7 @@ extern "C" void zj_launch_fix_only(const ZjParams &P, const ZjLaunch &L, hipStre
 
 extern "C" void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
 {
-    hipLaunchKernelGGL(zj_k1s_scan, dim3(L.nseg), dim3(256), 0, st, P);
+    zj_launch_scan(P, L, st);
     if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
     hipLaunchKernelGGL(zj_k1c_dcdiff, dim3((L.nblk256 + ZJ_K1C_NB - 1) / ZJ_K1C_NB), dim3(256), 0, st, P, L.nblk256);
     zj_launch_dcscan(P, L, st);

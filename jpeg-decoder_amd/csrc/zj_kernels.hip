@@ -152,19 +152,33 @@ struct ZjBitsLds {
     __device__ __forceinline__ uint32_t words_done(const uint32_t *col) const { return (uint32_t)(slot - col) >> 6; }
 };
 
-// Stage the window that holds stream word `w0` (a multiple of ZJ_WIN_WORDS) into this lane's column,
-// byte-swapped to MSB-first order, with two words of look-ahead and one spare slot behind them.
-__device__ __forceinline__ void zj_stage_window(const uint32_t *stream, uint32_t w0, uint32_t *col)
+// The sixteen stream words of one window as they were loaded.  A walk takes its windows in order and needs two words of
+// look-ahead behind each, which are the first two of the next window: so a step loads the window behind the one it
+// walks, takes the look-ahead from it and keeps it for the next step, and every 64 bytes of the stream are asked for
+// once (loading look-ahead words with each window asks for them twice, a step apart, and the second request has
+// mostly left the cache by then).
+struct ZjWinRegs {
+    uint4 a, b, c, d;
+    uint32_t win; // index of the window held, ZJ_NONE: none
+};
+
+__device__ __forceinline__ void zj_load_window(const uint32_t *stream, uint32_t win, ZjWinRegs &r)
 {
-    const uint4 *src = reinterpret_cast<const uint4 *>(stream + w0);
-    const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
-    const uint2 e = *reinterpret_cast<const uint2 *>(stream + w0 + 16);
+    const uint4 *src = reinterpret_cast<const uint4 *>(stream + win * ZJ_WIN_WORDS);
+    r.a = src[0]; r.b = src[1]; r.c = src[2]; r.d = src[3];
+    r.win = win;
+}
+
+// The window held in `r` into this lane's column, byte-swapped to MSB-first order, with the first two words of `next`
+// as look-ahead and one spare slot behind them.
+__device__ __forceinline__ void zj_store_window(const ZjWinRegs &r, const ZjWinRegs &next, uint32_t *col)
+{
 #define ZJ_SW(x) __builtin_bswap32(x)
-    col[0 * 64] = ZJ_SW(a.x); col[1 * 64] = ZJ_SW(a.y); col[2 * 64] = ZJ_SW(a.z); col[3 * 64] = ZJ_SW(a.w);
-    col[4 * 64] = ZJ_SW(b.x); col[5 * 64] = ZJ_SW(b.y); col[6 * 64] = ZJ_SW(b.z); col[7 * 64] = ZJ_SW(b.w);
-    col[8 * 64] = ZJ_SW(c.x); col[9 * 64] = ZJ_SW(c.y); col[10 * 64] = ZJ_SW(c.z); col[11 * 64] = ZJ_SW(c.w);
-    col[12 * 64] = ZJ_SW(d.x); col[13 * 64] = ZJ_SW(d.y); col[14 * 64] = ZJ_SW(d.z); col[15 * 64] = ZJ_SW(d.w);
-    col[16 * 64] = ZJ_SW(e.x); col[17 * 64] = ZJ_SW(e.y);
+    col[0 * 64] = ZJ_SW(r.a.x); col[1 * 64] = ZJ_SW(r.a.y); col[2 * 64] = ZJ_SW(r.a.z); col[3 * 64] = ZJ_SW(r.a.w);
+    col[4 * 64] = ZJ_SW(r.b.x); col[5 * 64] = ZJ_SW(r.b.y); col[6 * 64] = ZJ_SW(r.b.z); col[7 * 64] = ZJ_SW(r.b.w);
+    col[8 * 64] = ZJ_SW(r.c.x); col[9 * 64] = ZJ_SW(r.c.y); col[10 * 64] = ZJ_SW(r.c.z); col[11 * 64] = ZJ_SW(r.c.w);
+    col[12 * 64] = ZJ_SW(r.d.x); col[13 * 64] = ZJ_SW(r.d.y); col[14 * 64] = ZJ_SW(r.d.z); col[15 * 64] = ZJ_SW(r.d.w);
+    col[16 * 64] = ZJ_SW(next.a.x); col[17 * 64] = ZJ_SW(next.a.y);
 #undef ZJ_SW
 }
 
@@ -177,12 +191,19 @@ template <bool CANON>
 __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *stream, uint32_t *bitmap,
                                                    const uint32_t *lut, const ZjCanon *canon, uint32_t selw,
                                                    uint32_t bpm, ZjState &st, uint32_t win, uint32_t end,
-                                                   uint32_t *col, ZjBitsLds &bits, bool &primed)
+                                                   uint32_t *col, ZjBitsLds &bits, bool &primed, ZjWinRegs &kept)
 {
     uint32_t n = 0;
     if (run) {
         const uint32_t wbase = win * ZJ_WIN_WORDS;
-        zj_stage_window(stream, wbase, col);
+        // Only a walk's first step (and a lane that joins in later) finds another window in `kept` than the one it wants.
+        // The window behind may lie behind the payload or in the next segment's slot -- inside the arena either way (every
+        // slot has 96 bytes of slack, which hold the zeros the look-ahead must find, and the arena ends with 1040 more).
+        if (__any(kept.win != win)) zj_load_window(stream, win, kept);
+        ZjWinRegs next;
+        zj_load_window(stream, win + 1u, next);
+        zj_store_window(kept, next, col);
+        kept = next;
         if (!primed) { bits.init(col, wbase, st.p); primed = true; }
         else bits.rebase(col, wbase, st.p);
         const uint32_t wend = (win + 1u) * ZJ_WIN_BITS;
@@ -462,6 +483,8 @@ __device__ __forceinline__ void zj_k1a_body(const ZjParams &P, const ZjImgDev &i
     uint32_t *bitmap = reinterpret_cast<uint32_t *>(P.bitmap + sg.out_off);
     ZjBitsLds bits;
     bool primed = false;
+    ZjWinRegs kept;
+    kept.win = ZJ_NONE;
     ZjState st = {jl * SB, 0, 0};
     const bool act0 = sub_active(sg, jl, SB, pay);
     {
@@ -470,7 +493,7 @@ __device__ __forceinline__ void zj_k1a_body(const ZjParams &P, const ZjImgDev &i
             const uint32_t w = jl * NC + c;
             const bool run = act0 && w * ZJ_WIN_BITS < end; // every window that begins inside the payload gets its record and bitmap words
             if (!__any(run)) break;
-            const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
+            const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed, kept);
             if (run) rec[c * 64u + lane] = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
         }
     }
@@ -485,7 +508,7 @@ __device__ __forceinline__ void zj_k1a_body(const ZjParams &P, const ZjImgDev &i
             const uint32_t w = q * NC + c;
             const bool run = act && w * ZJ_WIN_BITS < end;
             if (!__any(run)) break;
-            const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
+            const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed, kept);
             if (run) {
                 const uint32_t nw = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
                 const uint32_t old = zj_load_coherent(&rec[c * 64u + tgt]);
@@ -529,6 +552,8 @@ __device__ __forceinline__ void zj_k1a_body_packed(const ZjParams &P, const ZjIm
     auto sub_stop = [&](uint32_t q) { const uint64_t e = (uint64_t)(q + 1u) * SB; return e < pay ? (uint32_t)e : pay; };
     ZjBitsLds bits;
     bool primed = false;
+    ZjWinRegs kept;
+    kept.win = ZJ_NONE;
     ZjState st = {jl * SB, 0, 0};
     const bool act0 = active(jl);
     {
@@ -537,7 +562,7 @@ __device__ __forceinline__ void zj_k1a_body_packed(const ZjParams &P, const ZjIm
             const uint32_t w = jl * NC + c;
             const bool run = act0 && c < NC && w * ZJ_WIN_BITS < end;
             if (!__any(run)) break;
-            const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
+            const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed, kept);
             if (run) rec[c * G + jl] = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
         }
     }
@@ -552,7 +577,7 @@ __device__ __forceinline__ void zj_k1a_body_packed(const ZjParams &P, const ZjIm
             const uint32_t w = tgt * NC + c;
             const bool run = act && c < NC && w * ZJ_WIN_BITS < end;
             if (!__any(run)) break;
-            const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed);
+            const uint32_t n = zj_window_step<CANON>(run, stream, bitmap, lut, canon, selw, sel.bpm, st, w, end, col, bits, primed, kept);
             if (run) {
                 const uint32_t nw = zj_pack_info(st, (w + 1u) * ZJ_WIN_BITS, n);
                 const uint32_t old = zj_load_coherent(&rec[c * G + tgt]);

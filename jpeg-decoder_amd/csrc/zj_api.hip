@@ -663,7 +663,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
             s.raw_end = raw_off[i] + end;
             const size_t rl = end - beg;
             s.out_off = ust_total;
-            s.out_cap = (uint32_t)(align_up(rl, 16) + 96);
+            s.out_cap = (uint32_t)align_up(align_up(rl, 16) + 96, 128); // segments start on 128-byte lines: the sync pass loads whole lines
             ust_total += s.out_cap;
             s.img = (uint32_t)i;
             zj_seg_layout((uint64_t)rl * 8u, subbits, small_target, &s.subbits, &s.nsub, &s.lanes);

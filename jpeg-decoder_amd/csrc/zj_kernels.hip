@@ -152,33 +152,34 @@ struct ZjBitsLds {
     __device__ __forceinline__ uint32_t words_done(const uint32_t *col) const { return (uint32_t)(slot - col) >> 6; }
 };
 
-// The sixteen stream words of one window as they were loaded.  A walk takes its windows in order and needs two words of
-// look-ahead behind each, which are the first two of the next window: so a step loads the window behind the one it
-// walks, takes the look-ahead from it and keeps it for the next step, and every 64 bytes of the stream are asked for
-// once (loading look-ahead words with each window asks for them twice, a step apart, and the second request has
-// mostly left the cache by then).
-struct ZjWinRegs {
-    uint4 a, b, c, d;
-    uint32_t win; // index of the window held, ZJ_NONE: none
+// The 32 stream words of one 128-byte line -- two windows -- as they were loaded.  Memory hands out whole lines: a walk
+// that asks for 64 bytes per step gets every line twice, a step apart, when the first copy has left the cache.  So a
+// walk keeps the line it is in: the even window of a line is staged from the registers alone (its two words of
+// look-ahead are the odd window's first two), the odd window's step loads the next line for its look-ahead and keeps
+// it.  Every line of the stream is asked for once.  (Segments start on line boundaries in the unstuffed arena.)
+struct ZjLineRegs {
+    uint4 v[8];
+    uint32_t line; // index of the line held (window index / 2), ZJ_NONE: none
 };
 
-__device__ __forceinline__ void zj_load_window(const uint32_t *stream, uint32_t win, ZjWinRegs &r)
+__device__ __forceinline__ void zj_load_line(const uint32_t *stream, uint32_t line, ZjLineRegs &r)
 {
-    const uint4 *src = reinterpret_cast<const uint4 *>(stream + win * ZJ_WIN_WORDS);
-    r.a = src[0]; r.b = src[1]; r.c = src[2]; r.d = src[3];
-    r.win = win;
+    const uint4 *src = reinterpret_cast<const uint4 *>(stream + line * (2u * ZJ_WIN_WORDS));
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = src[i];
+    r.line = line;
 }
 
-// The window held in `r` into this lane's column, byte-swapped to MSB-first order, with the first two words of `next`
-// as look-ahead and one spare slot behind them.
-__device__ __forceinline__ void zj_store_window(const ZjWinRegs &r, const ZjWinRegs &next, uint32_t *col)
+// Sixteen words and two of look-ahead into this lane's column, byte-swapped to MSB-first order (one spare slot follows).
+__device__ __forceinline__ void zj_store_window(const uint4 &a, const uint4 &b, const uint4 &c, const uint4 &d, uint32_t la0, uint32_t la1,
+                                                uint32_t *col)
 {
 #define ZJ_SW(x) __builtin_bswap32(x)
-    col[0 * 64] = ZJ_SW(r.a.x); col[1 * 64] = ZJ_SW(r.a.y); col[2 * 64] = ZJ_SW(r.a.z); col[3 * 64] = ZJ_SW(r.a.w);
-    col[4 * 64] = ZJ_SW(r.b.x); col[5 * 64] = ZJ_SW(r.b.y); col[6 * 64] = ZJ_SW(r.b.z); col[7 * 64] = ZJ_SW(r.b.w);
-    col[8 * 64] = ZJ_SW(r.c.x); col[9 * 64] = ZJ_SW(r.c.y); col[10 * 64] = ZJ_SW(r.c.z); col[11 * 64] = ZJ_SW(r.c.w);
-    col[12 * 64] = ZJ_SW(r.d.x); col[13 * 64] = ZJ_SW(r.d.y); col[14 * 64] = ZJ_SW(r.d.z); col[15 * 64] = ZJ_SW(r.d.w);
-    col[16 * 64] = ZJ_SW(next.a.x); col[17 * 64] = ZJ_SW(next.a.y);
+    col[0 * 64] = ZJ_SW(a.x); col[1 * 64] = ZJ_SW(a.y); col[2 * 64] = ZJ_SW(a.z); col[3 * 64] = ZJ_SW(a.w);
+    col[4 * 64] = ZJ_SW(b.x); col[5 * 64] = ZJ_SW(b.y); col[6 * 64] = ZJ_SW(b.z); col[7 * 64] = ZJ_SW(b.w);
+    col[8 * 64] = ZJ_SW(c.x); col[9 * 64] = ZJ_SW(c.y); col[10 * 64] = ZJ_SW(c.z); col[11 * 64] = ZJ_SW(c.w);
+    col[12 * 64] = ZJ_SW(d.x); col[13 * 64] = ZJ_SW(d.y); col[14 * 64] = ZJ_SW(d.z); col[15 * 64] = ZJ_SW(d.w);
+    col[16 * 64] = ZJ_SW(la0); col[17 * 64] = ZJ_SW(la1);
 #undef ZJ_SW
 }
 
@@ -191,19 +192,24 @@ template <bool CANON>
 __device__ __forceinline__ uint32_t zj_window_step(bool run, const uint32_t *stream, uint32_t *bitmap,
                                                    const uint32_t *lut, const ZjCanon *canon, uint32_t selw,
                                                    uint32_t bpm, ZjState &st, uint32_t win, uint32_t end,
-                                                   uint32_t *col, ZjBitsLds &bits, bool &primed, ZjWinRegs &kept)
+                                                   uint32_t *col, ZjBitsLds &bits, bool &primed, ZjLineRegs &kept)
 {
     uint32_t n = 0;
     if (run) {
         const uint32_t wbase = win * ZJ_WIN_WORDS;
-        // Only a walk's first step (and a lane that joins in later) finds another window in `kept` than the one it wants.
-        // The window behind may lie behind the payload or in the next segment's slot -- inside the arena either way (every
+        // Only a walk's first step (and a lane that joins in later) finds another line in `kept` than the one it is in.
+        // The line behind may lie behind the payload or in the next segment's slot -- inside the arena either way (every
         // slot has 96 bytes of slack, which hold the zeros the look-ahead must find, and the arena ends with 1040 more).
-        if (__any(kept.win != win)) zj_load_window(stream, win, kept);
-        ZjWinRegs next;
-        zj_load_window(stream, win + 1u, next);
-        zj_store_window(kept, next, col);
-        kept = next;
+        const uint32_t line = win >> 1;
+        if (__any(kept.line != line)) zj_load_line(stream, line, kept);
+        if ((win & 1u) == 0u) {
+            zj_store_window(kept.v[0], kept.v[1], kept.v[2], kept.v[3], kept.v[4].x, kept.v[4].y, col);
+        } else {
+            ZjLineRegs next;
+            zj_load_line(stream, line + 1u, next);
+            zj_store_window(kept.v[4], kept.v[5], kept.v[6], kept.v[7], next.v[0].x, next.v[0].y, col);
+            kept = next;
+        }
         if (!primed) { bits.init(col, wbase, st.p); primed = true; }
         else bits.rebase(col, wbase, st.p);
         const uint32_t wend = (win + 1u) * ZJ_WIN_BITS;
@@ -483,8 +489,8 @@ __device__ __forceinline__ void zj_k1a_body(const ZjParams &P, const ZjImgDev &i
     uint32_t *bitmap = reinterpret_cast<uint32_t *>(P.bitmap + sg.out_off);
     ZjBitsLds bits;
     bool primed = false;
-    ZjWinRegs kept;
-    kept.win = ZJ_NONE;
+    ZjLineRegs kept;
+    kept.line = ZJ_NONE;
     ZjState st = {jl * SB, 0, 0};
     const bool act0 = sub_active(sg, jl, SB, pay);
     {
@@ -552,8 +558,8 @@ __device__ __forceinline__ void zj_k1a_body_packed(const ZjParams &P, const ZjIm
     auto sub_stop = [&](uint32_t q) { const uint64_t e = (uint64_t)(q + 1u) * SB; return e < pay ? (uint32_t)e : pay; };
     ZjBitsLds bits;
     bool primed = false;
-    ZjWinRegs kept;
-    kept.win = ZJ_NONE;
+    ZjLineRegs kept;
+    kept.line = ZJ_NONE;
     ZjState st = {jl * SB, 0, 0};
     const bool act0 = active(jl);
     {

@@ -912,6 +912,12 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     b->L.nsmall = (uint32_t)small_seg.size();
     b->L.ndtiles = (uint32_t)nbigd;
     b->L.ndsmall = (uint32_t)dsmall_seg.size();
+    {
+        // the DC scan by whole segments pays when the segments fill the GPU on their own and are long enough to occupy a
+        // workgroup of 1024 lanes; one huge segment, or many short ones, are better off in tiles
+        const size_t nlong = b->segs.size() - dsmall_seg.size();
+        b->L.dc_by_segment = nlong >= 256u && nbigd >= nlong * 8u && nbigd <= nlong * 256u;
+    }
     b->L.nstrips = (uint32_t)strip_grp_all.size();
     b->L.fix_iters = 1;
     ctx->err_code = ZJ_OK;

@@ -74,6 +74,7 @@ struct ZjLaunch {
     uint32_t nsmall;  // segments unstuffed by the one-wavefront form; their entries of tile_seg follow the `ntiles` others
     uint32_t ndsmall; // segments of at most 64 MCUs, scanned by one wavefront each; their entries of dtile_seg follow the `ndtiles` others
     uint32_t ndmulti; // segments of more than one DC-scan tile
+    uint32_t dc_by_segment; // many long segments (a batch of images without restart markers): one workgroup scans a whole segment
     uint32_t npacked; // chunks shared by several short segments (the packed form of the sync kernel)
     uint32_t k2_first[ZJ_K2_CLASSES], k2_count[ZJ_K2_CLASSES]; // stage-2 workgroups per layout (2x2, 1x1, 2x1, 1x2, one component)
     int fix_iters;

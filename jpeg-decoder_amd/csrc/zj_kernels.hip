@@ -860,28 +860,53 @@ __global__ __launch_bounds__(1024) void zj_k1s_scan_few(ZjParams P)
 }
 
 // ---------------------------------------------------------------------------------- k1p: positions
-// One lane per window: turns the window's bitmap words into entries of the block position list.
+// Turns the bitmap words into entries of the block position list.  A workgroup takes 256 windows of a segment; a lane
+// takes a quarter of a window (four words) at a time, so that the 64 lanes of a wavefront load 1 KiB side by side, and
+// learns how many blocks begin in the quarters before its own from the other three lanes of its quad.
 __global__ __launch_bounds__(256) void zj_k1p_positions(ZjParams P)
 {
     const uint32_t s = P.ptile_seg[blockIdx.x];
     const ZjSegDev sg = P.segs[s];
     const uint32_t pay = P.seg_payload_bits[s];
     const uint32_t nwin = min(sg.nsub * sg.nc, (pay + ZJ_WIN_BITS - 1u) / ZJ_WIN_BITS);
-    const uint32_t wi = (blockIdx.x - sg.first_ptile) * 256u + threadIdx.x;
-    if (wi >= nwin) return;
-    const uint4 *src = reinterpret_cast<const uint4 *>(P.bitmap + sg.out_off) + (size_t)wi * 4u;
-    const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
-    const uint32_t w[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-    uint32_t g = P.wbase[sg.first_win + wi];
+    const uint32_t w0 = (blockIdx.x - sg.first_ptile) * 256u; // the workgroup's first window
+    if (w0 >= nwin) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(P.bitmap + sg.out_off) + (size_t)w0 * 4u;
+    const uint32_t *wbase = P.wbase + sg.first_win + w0;
     uint32_t *pos = P.blockpos + sg.first_block;
+    const uint32_t quarter = threadIdx.x & 3u;
+    uint4 q[4];
+    uint32_t g[4];
+    // all loads first, unconditional (a quarter behind the last window reads the tile's first one and is ignored)
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        uint32_t m = w[i];
-        while (m) {
-            const uint32_t bit = (uint32_t)__builtin_ctz(m);
-            m &= m - 1u;
-            if (g < sg.nblocks) pos[g] = wi * ZJ_WIN_BITS + (uint32_t)i * 32u + bit;
-            g++;
+    for (uint32_t it = 0; it < 4u; it++) {
+        const uint32_t idx = it * 256u + threadIdx.x;
+        const bool ok = w0 + (idx >> 2) < nwin;
+        q[it] = src[ok ? idx : 0u];
+        g[it] = wbase[ok ? idx >> 2 : 0u];
+    }
+#pragma unroll
+    for (uint32_t it = 0; it < 4u; it++) {
+        const uint32_t idx = it * 256u + threadIdx.x;
+        const uint32_t wi = w0 + (idx >> 2);
+        const bool ok = wi < nwin;
+        const uint32_t w[4] = {ok ? q[it].x : 0u, ok ? q[it].y : 0u, ok ? q[it].z : 0u, ok ? q[it].w : 0u};
+        const int c = (int)(__popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]));
+        // blocks that begin in quarters 0, 1, 2 of this lane's window (quad_perm broadcasts of one lane of the quad)
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_mov_dpp(c, 0x00, 0xF, 0xF, true);
+        const uint32_t c1 = (uint32_t)__builtin_amdgcn_mov_dpp(c, 0x55, 0xF, 0xF, true);
+        const uint32_t c2 = (uint32_t)__builtin_amdgcn_mov_dpp(c, 0xAA, 0xF, 0xF, true);
+        uint32_t gi = g[it] + (quarter > 0u ? c0 : 0u) + (quarter > 1u ? c1 : 0u) + (quarter > 2u ? c2 : 0u);
+        const uint32_t bit0 = wi * ZJ_WIN_BITS + quarter * 128u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t m = w[i];
+            while (m) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(m);
+                m &= m - 1u;
+                if (gi < sg.nblocks) pos[gi] = bit0 + (uint32_t)i * 32u + bit;
+                gi++;
+            }
         }
     }
 }
@@ -1077,6 +1102,71 @@ __global__ __launch_bounds__(256) void zj_k1d_dcscan(ZjParams P)
         out[k] = v & 0xFFFFu;
     }
     zj_dc_tile_store(da, m, nmcu, bpm, out);
+}
+
+// The three launches above as one, for batches of many long segments (thousands of images without restart markers): a
+// workgroup of 1024 lanes takes a whole segment, four consecutive MCUs per lane and step, so the differences are
+// read once and the tile sums never leave the workgroup.
+__global__ __launch_bounds__(1024) void zj_k1d_dcscan_seg(ZjParams P)
+{
+    __shared__ uint32_t wsum[3][16];
+    const uint32_t s = blockIdx.x;
+    const ZjSegDev sg = P.segs[s];
+    const ZjImgDev im = P.imgs[sg.img]; // by value: a reference would be read again after every store
+    const uint32_t bpm = im.bpm, compsel = im.compsel;
+    const uint32_t nmcu = sg.nblocks / bpm;
+    if (nmcu <= 64u) return; // the one-wavefront form takes these
+    int16_t *da = P.dcabs + sg.first_block; // holds the differences on entry
+    constexpr uint32_t K = 4u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t carry[3] = {0, 0, 0};
+    for (uint32_t m0 = 0; m0 < nmcu; m0 += 1024u * K) {
+        const uint32_t m = m0 + threadIdx.x * K;
+        ZjDcTile t[K];
+        uint32_t loc[3] = {0, 0, 0};
+#pragma unroll
+        for (uint32_t k = 0; k < K; k++) {
+            t[k] = zj_dc_tile_load(da, m + k, nmcu, bpm, compsel);
+#pragma unroll
+            for (uint32_t cc = 0; cc < 3u; cc++) loc[cc] += t[k].loc[cc];
+        }
+        uint32_t inc[3];
+#pragma unroll
+        for (uint32_t cc = 0; cc < 3u; cc++) inc[cc] = wave_incl_scan(loc[cc], lane);
+        __syncthreads(); // the sums of the step before have been read
+        if (lane == 63u) {
+#pragma unroll
+            for (uint32_t cc = 0; cc < 3u; cc++) wsum[cc][wave] = inc[cc];
+        }
+        __syncthreads();
+        uint32_t run[3];
+#pragma unroll
+        for (uint32_t cc = 0; cc < 3u; cc++) {
+            uint32_t off = 0, tot = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 16u; w++) {
+                const uint32_t v = wsum[cc][w];
+                if (w < wave) off += v;
+                tot += v;
+            }
+            run[cc] = carry[cc] + off + inc[cc] - loc[cc];
+            carry[cc] += tot;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < K; k++) {
+            uint32_t out[6];
+#pragma unroll
+            for (uint32_t j = 0; j < 6u; j++) {
+                const uint32_t c = (compsel >> (2u * j)) & 3u;
+                uint32_t v = 0;
+#pragma unroll
+                for (uint32_t cc = 0; cc < 3u; cc++)
+                    if (c == cc && j < bpm) { run[cc] += t[k].d[j]; v = run[cc]; }
+                out[j] = v & 0xFFFFu;
+            }
+            zj_dc_tile_store(da, m + k, nmcu, bpm, out);
+        }
+    }
 }
 
 // The same for segments of at most 64 MCUs (short restart intervals), which the planner lists apart: one
@@ -2177,11 +2267,15 @@ static void zj_launch_scan(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
 
 static void zj_launch_dcscan(const ZjParams &P, const ZjLaunch &L, hipStream_t st)
 {
-    if (L.ndmulti) { // segments of more than one tile: their tile sums first
-        hipLaunchKernelGGL(zj_k1d_tilesum, dim3(L.ndtiles), dim3(256), 0, st, P);
-        hipLaunchKernelGGL(zj_k1d_tilescan, dim3(L.nseg), dim3(256), 0, st, P);
+    if (L.dc_by_segment) {
+        hipLaunchKernelGGL(zj_k1d_dcscan_seg, dim3(L.nseg), dim3(1024), 0, st, P);
+    } else {
+        if (L.ndmulti) { // segments of more than one tile: their tile sums first
+            hipLaunchKernelGGL(zj_k1d_tilesum, dim3(L.ndtiles), dim3(256), 0, st, P);
+            hipLaunchKernelGGL(zj_k1d_tilescan, dim3(L.nseg), dim3(256), 0, st, P);
+        }
+        if (L.ndtiles) hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.ndtiles), dim3(256), 0, st, P);
     }
-    if (L.ndtiles) hipLaunchKernelGGL(zj_k1d_dcscan, dim3(L.ndtiles), dim3(256), 0, st, P);
     if (L.ndsmall) hipLaunchKernelGGL(zj_k1d_dcscan_small, dim3((L.ndsmall + 3u) / 4u), dim3(256), 0, st, P, L.ndtiles, L.ndsmall);
 }
 

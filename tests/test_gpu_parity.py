@@ -249,6 +249,27 @@ def test_large_batches_use_long_write_runs(ctx):
     b.close()
 
 
+def test_many_long_segments_scan_their_dc_values_by_segment(ctx):
+    """A batch of hundreds of images without restart markers takes the DC scan that gives a whole segment to one
+    workgroup: every layout (6, 3, 4 and 1 blocks per MCU), segments of one step (up to 4096 MCUs) and of several."""
+    import torch
+    files = [synth.encode(1920, 1080, 2, 2, seed=81), synth.encode(640, 480, 1, 1, seed=82), synth.encode(1024, 512, 2, 1, seed=83),
+             synth.encode(512, 1024, 1, 2, seed=84), synth.encode(520, 520, 0, 0, seed=85), synth.encode(1280, 720, 1, 1, 80, seed=86)]
+    refs = [oracle.decode(f) for f in files]
+    imgs = [J.ParsedImage(files[i % 6]) for i in range(300)]
+    b = J.Batch(ctx, imgs)
+    outs = b.alloc_rgb()
+    b.decode(outs)
+    st = b.finish()
+    assert not st.any()
+    want = [torch.from_numpy(r.rgb).to("cuda:0") for r in refs]
+    for i, im in enumerate(imgs):
+        assert torch.equal(outs[i][:, : im.width * 3].reshape(im.height, im.width, 3), want[i % 6]), i
+    for i in (0, 1, 2, 3, 4, 5, 299):
+        assert np.array_equal(b.coefficients(i), refs[i % 6].qcoef)
+    b.close()
+
+
 def test_restart_band_equals_rows_of_full_decode(ctx):
     """The multi-GPU split of one restart-marked image: every band decoded on its own equals the same
     rows of the whole image."""

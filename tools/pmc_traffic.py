@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GROUP = {"k1c_dcdiff": "k1d_dcscan", "k1d_tilesum": "k1d_dcscan", "k1d_tilescan": "k1d_dcscan", "k1d_dcscan_small": "k1d_dcscan",
-         "k1a_sync_packed": "k1a_sync"}  # timed together by the library
+         "k1d_dcscan_seg": "k1d_dcscan", "k1s_scan_few": "k1s_scan", "k1a_sync_packed": "k1a_sync"}  # timed together by the library
 KERNEL_SOURCES = ["zj_kernels.hip", "zj_core.h", "zj_dev.h"]
 
 

@@ -465,6 +465,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     b->imgs.resize(n);
     b->unsupported.assign(n, 0);
     std::vector<uint32_t> chunk_seg, blk256_img, k1w_img, ptile_seg, tile_seg, small_seg, dtile_seg, dsmall_seg;
+    size_t unstuff_tiles = 0; // tiles of the unstuff pass's 128-thread form over all segments: one look-back word each
     uint64_t nwin_total = 0;
     std::vector<uint32_t> k2_grp[ZJ_K2_CLASSES], k2_img[ZJ_K2_CLASSES]; // stage-2 workgroups per sampling layout
     std::vector<uint16_t> luts;
@@ -482,11 +483,16 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     uint64_t mcus_total = 0;
     for (size_t i = 0; i < n; i++) {
         if (!zj_image_supported(&images[i])) continue;
+        if (images[i].scan_len >= 0xF0000000ull) { ctx->err = "scan of 4 GiB or more"; ctx->err_code = ZJ_E_INVALID; zj_batch_destroy(b); return nullptr; } // the kernels count bytes inside a segment in 32 bits
         mcus_total += zj_image_mcus(&images[i]);
         raw_off[i] = raw_total;
         raw_total += align_up(images[i].scan_len, 16) + 16;
     }
     b->scan_at.assign(raw_off.begin(), raw_off.end());
+    // Tiles per workgroup of the unstuff pass (a workgroup takes tiles of its segment until none is left, asking for the next
+    // one's bytes while it works on this one): up to ZJ_UNSTUFF_REP when the batch has several times more tiles than the GPU
+    // holds at once (ten per CU), one when it has fewer -- a single image wants every tile in flight at the same moment.
+    const uint32_t unstuff_rep = (uint32_t)std::min<uint64_t>(ZJ_UNSTUFF_REP, std::max<uint64_t>(1, raw_total / ZJ_UNSTUFF_TILE / 2560u));
     uint8_t *raw = dev_alloc<uint8_t>(b, raw_total + 1040, false);
     if (!raw) { zj_batch_destroy(b); return nullptr; }
     {
@@ -697,9 +703,11 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
                 s.ntiles = 1;
                 small_seg.push_back((uint32_t)b->segs.size());
             } else {
-                s.first_tile = (uint32_t)tile_seg.size();
+                s.first_tile = (uint32_t)unstuff_tiles;
                 s.ntiles = (uint32_t)((s.raw_end - (s.raw_begin & ~15ull) + ZJ_UNSTUFF_TILE - 1u) / ZJ_UNSTUFF_TILE);
-                for (uint32_t t = 0; t < s.ntiles; t++) tile_seg.push_back((uint32_t)b->segs.size());
+                unstuff_tiles += s.ntiles;
+                // a workgroup of the unstuff pass takes tiles of its segment until none is left
+                for (uint32_t t = 0; t < s.ntiles; t += unstuff_rep) tile_seg.push_back((uint32_t)b->segs.size());
             }
             s.first_ptile = (uint32_t)ptile_seg.size();
             for (uint64_t w = 0; w < (uint64_t)s.nsub * s.nc; w += 256u) ptile_seg.push_back((uint32_t)b->segs.size());
@@ -818,7 +826,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     P.raw = raw;
     // what every decode call clears, in one block so that it is one fill: flags, status words, the unstuff pass's look-back
     // words and tickets
-    const size_t nbig_tiles = tile_seg.size() - small_seg.size();
+    const size_t nbig_tiles = unstuff_tiles;
     const size_t status_words = align_up(n ? n : 1, 4);
     const size_t clear_bytes = 16 + status_words * 4 + (nbig_tiles + 1) * 8 + (b->segs.size() + 2) * 4;
     uint8_t *clear_block = dev_alloc<uint8_t>(b, clear_bytes, true);
@@ -954,7 +962,7 @@ extern "C" int zj_workspace_estimate(const zj_image *images, size_t n, size_t *p
         plan += 2 * ZJ_SET_ENTRIES * 2 + ZJ_PSET_ENTRIES * 4 + 2 * ZJ_WT_ENTRIES * 4 + 512 + 4 * sizeof(ZjCanon) + 3 * 64 * 2;  // a table set (four forms) and quantisation tables of its own
         plan += sizeof(ZjMarkImg) + 8 * mtiles + 4 + 4 * (S + 1);           // restart-marker search
         plan += 8 * (utiles + S) + 64; // look-back words and tickets of the unstuff pass, cleared with the status words
-        scr += 16 * dtiles + 2 * (len + 112 * S) + 8 * S + 8 * win + 7 * B + 128 * B;
+        scr += 16 * dtiles + 2 * (len + 240 * S) + 8 * S + 8 * win + 7 * B + 128 * B; // a segment's slot: its bytes, 96 of slack, rounded up to 16 and then to a 128-byte line
     }
     if (plan_bytes) *plan_bytes = (size_t)(plan + plan / 64);
     if (scratch_bytes) *scratch_bytes = (size_t)(scr + scr / 64);

@@ -67,6 +67,9 @@ struct ZjParams {
 __host__ __device__ constexpr uint32_t zj_k2_wave_mcus(uint32_t hs, uint32_t vs) { return vs == 2u ? 4u : 8u; }
 #define ZJ_K2_CLASSES 5
 #define ZJ_UNSTUFF_TILE 15872u // raw bytes per workgroup of the unstuff pass: 128 threads x 31 words
+#ifndef ZJ_UNSTUFF_REP
+#define ZJ_UNSTUFF_REP 8u // tiles per workgroup of the unstuff pass (a workgroup takes tiles of its segment until none is left)
+#endif
 #define ZJ_UNSTUFF_SMALL 3840u // and of its one-wavefront form for segments that fit into one such tile: 64 threads x 15 words
 
 struct ZjLaunch {

@@ -267,188 +267,231 @@ __global__ __launch_bounds__(ZJ_K0_THREADS) void zj_k0_unstuff(ZjParams P, uint3
     const uint32_t tid = threadIdx.x;
     // The workgroup's segment is fixed by its index; which of the segment's tiles it takes is decided by a
     // ticket per segment (one counter for the whole grid would serialise a quarter of a million atomics
-    // on one address).
+    // on one address).  A workgroup takes tiles until the segment has none left, and asks for the next tile's
+    // ticket and bytes while it still works on this one: what limits the pass is how long a tile occupies its
+    // share of LDS, and that no longer includes the trips for its ticket and its bytes.
     const uint32_t s = P.tile_seg[tile0 + blockIdx.x];
     const ZjSegDev sg = P.segs[s];
-    if (!SINGLE) {
-        if (tid == 0) s_tile = atomicAdd(&P.seg_ticket[s], 1u);
-        __syncthreads();
-    }
-    const uint32_t tj = SINGLE ? 0u : s_tile;
-    const uint32_t tile = sg.first_tile + tj;
-    const uint64_t a0 = sg.raw_begin & ~15ull;
-    const uint64_t t0 = a0 + (uint64_t)tj * ZJ_K0_TILE;
-    const uint64_t my = t0 + (uint64_t)tid * (ZJ_K0_WORDS * 4u);
-    const uint8_t *raw = P.raw;
-
-    // bytes of this thread that belong to the segment: [lo, hi) of 0..NB (signed differences, clamped)
+    // everything below is counted in bytes from the 16-byte line at or below the segment's first byte: a segment is shorter
+    // than 4 GiB (the planner sees to it), so 32 bits do, and a lane's addresses are one register each
+    const uint8_t *raw = P.raw + (sg.raw_begin & ~15ull);
+    const uint32_t seg_beg = (uint32_t)(sg.raw_begin & 15ull), seg_end = (uint32_t)(sg.raw_end - (sg.raw_begin & ~15ull));
     constexpr int NB = (int)(ZJ_K0_WORDS * 4u);
-    const int64_t dlo = (int64_t)sg.raw_begin - (int64_t)my, dhi = (int64_t)sg.raw_end - (int64_t)my;
-    const uint32_t lo = dlo <= 0 ? 0u : (dlo >= NB ? (uint32_t)NB : (uint32_t)dlo);
-    const uint32_t hi = dhi <= 0 ? 0u : (dhi >= NB ? (uint32_t)NB : (uint32_t)dhi);
+    constexpr uint32_t NPC = ZJ_K0_TILE / 16u, NLD = (NPC + ZJ_K0_THREADS - 1u) / ZJ_K0_THREADS;
+    const bool nonempty = seg_end > 0u;
+    const uint32_t lim = nonempty ? ((seg_end - 1u) & ~15u) : 0u; // offset of the last piece with bytes of the segment
     // The byte before this thread's first byte, and the tile in 16-byte pieces (coalesced) on its way into
     // LDS, where every thread then picks up its words.  The loads are unconditional (addresses clamped
     // into the segment, results masked afterwards) so that all of them are in flight before the first is
     // waited for: one trip to memory per tile, not one per piece.
-    const bool has_before = dlo < 0 && dhi >= 0;
-    const uint32_t pfb = raw[has_before ? my - 1 : a0];
-    constexpr uint32_t NPC = ZJ_K0_TILE / 16u, NLD = (NPC + ZJ_K0_THREADS - 1u) / ZJ_K0_THREADS;
-    const bool nonempty = sg.raw_end > a0;
-    const uint64_t lim = nonempty ? ((sg.raw_end - 1u - a0) & ~15ull) : 0ull; // offset of the last piece with bytes of the segment
     uint4 ld[NLD];
+    uint32_t pfb;
+    auto request = [&](uint32_t tj) {
+        const uint32_t my = tj * ZJ_K0_TILE + tid * (ZJ_K0_WORDS * 4u);
+        pfb = raw[(my > seg_beg && my <= seg_end) ? my - 1u : 0u];
 #pragma unroll
-    for (uint32_t i = 0; i < NLD; i++) {
-        const uint64_t po = (uint64_t)tj * ZJ_K0_TILE + 16u * (tid + i * ZJ_K0_THREADS);
-        ld[i] = *reinterpret_cast<const uint4 *>(raw + a0 + (po < lim ? po : lim));
+        for (uint32_t i = 0; i < NLD; i++) {
+            const uint32_t po = tj * ZJ_K0_TILE + 16u * (tid + i * ZJ_K0_THREADS);
+            ld[i] = *reinterpret_cast<const uint4 *>(raw + (po < lim ? po : lim));
+        }
+    };
+    uint32_t tj = 0;
+    if (!SINGLE) {
+        if (tid == 0) s_tile = atomicAdd(&P.seg_ticket[s], 1u);
+        __syncthreads();
+        tj = s_tile;
+        if (tj >= sg.ntiles) return; // uniform: the segment's tiles are all taken
+        __syncthreads(); // everyone has read the ticket before it is replaced below
     }
+    request(tj);
+    for (;;) {
+        // the thread index as a value the compiler takes for new in every turn: what is derived from it is worked out again per
+        // tile (a few instructions) instead of being kept in registers across the whole loop (dozens of them)
+        uint32_t t = tid;
+        asm volatile("" : "+v"(t));
+        uint32_t next_ticket = 0; // lane 0: the ticket of the tile after this one, asked for now, passed on at the scan's barriers
+        if (!SINGLE && t == 0) next_ticket = atomicAdd(&P.seg_ticket[s], 1u);
+        const uint32_t tile = sg.first_tile + tj;
+        const uint32_t my = tj * ZJ_K0_TILE + t * (ZJ_K0_WORDS * 4u);
+        // bytes of this thread that belong to the segment: [lo, hi) of 0..NB (signed differences, clamped)
+        const int64_t dlo = (int64_t)seg_beg - (int64_t)my, dhi = (int64_t)seg_end - (int64_t)my;
+        const uint32_t lo = dlo <= 0 ? 0u : (dlo >= NB ? (uint32_t)NB : (uint32_t)dlo);
+        const uint32_t hi = dhi <= 0 ? 0u : (dhi >= NB ? (uint32_t)NB : (uint32_t)dhi);
+        const bool has_before = dlo < 0 && dhi >= 0;
 #pragma unroll
-    for (uint32_t i = 0; i < NLD; i++) {
-        const uint32_t pc = tid + i * ZJ_K0_THREADS;
-        const uint64_t po = (uint64_t)tj * ZJ_K0_TILE + 16u * pc;
-        const bool ok = nonempty && po <= lim;
-        const uint4 v = make_uint4(ok ? ld[i].x : 0u, ok ? ld[i].y : 0u, ok ? ld[i].z : 0u, ok ? ld[i].w : 0u);
-        if (pc < NPC) reinterpret_cast<uint4 *>(buf)[pc] = v; // unconditional: a store under `ok` makes the compiler wait for each load in turn
-    }
-    uint32_t pf = has_before && pfb == 0xFFu; // is the byte before this thread's first byte an FF of the segment
-    __syncthreads();
-    // A wavefront none of whose bytes belong to the segment (most of a tile, when restart intervals are
-    // short) only takes part in the barriers and the scan.
-    const bool wave_empty = __all(lo >= hi);
-    uint32_t w[ZJ_K0_WORDS];
-    if (!wave_empty) {
+        for (uint32_t i = 0; i < NLD; i++) {
+            const uint32_t pc = t + i * ZJ_K0_THREADS;
+            const uint32_t po = tj * ZJ_K0_TILE + 16u * pc;
+            const bool ok = nonempty && po <= lim;
+            const uint4 v = make_uint4(ok ? ld[i].x : 0u, ok ? ld[i].y : 0u, ok ? ld[i].z : 0u, ok ? ld[i].w : 0u);
+            if (pc < NPC) reinterpret_cast<uint4 *>(buf)[pc] = v; // unconditional: a store under `ok` makes the compiler wait for each load in turn
+        }
+        uint32_t pf = has_before && pfb == 0xFFu; // is the byte before this thread's first byte an FF of the segment
+        __syncthreads();
+        // A wavefront none of whose bytes belong to the segment (most of a tile, when restart intervals are
+        // short) only takes part in the barriers and the scan.
+        const bool wave_empty = __all(lo >= hi);
+        uint32_t w[ZJ_K0_WORDS];
 #pragma unroll
-        for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) w[j] = reinterpret_cast<const uint32_t *>(buf)[tid * ZJ_K0_WORDS + j];
-    }
+        for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) w[j] = 0; // (defined on every path: otherwise the values of the tile before count as live)
+        if (!wave_empty) {
+#pragma unroll
+            for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) w[j] = reinterpret_cast<const uint32_t *>(buf)[t * ZJ_K0_WORDS + j];
+        }
 
-    // kill[j]: bit 7 of byte k set when byte 4j+k is not kept (a stuffed 00, or outside the segment)
-    uint32_t kill[ZJ_K0_WORDS];
-    uint32_t n;
-    if (__all(lo == 0u && hi == (uint32_t)NB)) {
-        // whole wavefront inside the segment (all but the first and last tile): word-parallel byte tests
-        uint32_t fprev = pf ? 0x80000000u : 0u, ndrop = 0;
+        // kill[j]: bit 7 of byte k set when byte 4j+k is not kept (a stuffed 00, or outside the segment)
+        uint32_t kill[ZJ_K0_WORDS];
 #pragma unroll
-        for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) {
-            const uint32_t x = w[j], y = ~x;
-            const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); // bytes equal to 00
-            const uint32_t f = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu); // bytes equal to FF
-            const uint32_t before = __builtin_amdgcn_alignbyte(f, fprev, 3);          // FF flag of the byte before
-            kill[j] = z & before;
-            ndrop += __popc(kill[j]);
-            fprev = f;
+        for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) kill[j] = 0;
+        uint32_t n;
+        if (__all(lo == 0u && hi == (uint32_t)NB)) {
+            // whole wavefront inside the segment (all but the first and last tile): word-parallel byte tests
+            uint32_t fprev = pf ? 0x80000000u : 0u, ndrop = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) {
+                const uint32_t x = w[j], y = ~x;
+                const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); // bytes equal to 00
+                const uint32_t f = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu); // bytes equal to FF
+                const uint32_t before = __builtin_amdgcn_alignbyte(f, fprev, 3);          // FF flag of the byte before
+                kill[j] = z & before;
+                ndrop += __popc(kill[j]);
+                fprev = f;
+            }
+            n = (uint32_t)NB - ndrop;
+        } else if (!wave_empty) {
+            // first and last tile of a segment: the same word-parallel tests, with the bytes outside [lo, hi)
+            // masked -- they are not kept, and an FF among them is not "the byte before"
+            uint32_t fprev = pf ? 0x80000000u : 0u, ndrop = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) {
+                const int32_t lj = (int32_t)lo - (int32_t)(4u * j), hj = (int32_t)hi - (int32_t)(4u * j);
+                const uint32_t l4 = lj <= 0 ? 0u : (lj >= 4 ? 4u : (uint32_t)lj), h4 = hj <= 0 ? 0u : (hj >= 4 ? 4u : (uint32_t)hj);
+                const uint32_t ge = (uint32_t)(0x80808080ull << (8u * l4)), lt = 0x80808080u & ~(uint32_t)(0x80808080ull << (8u * h4));
+                const uint32_t inm = ge & lt; // bit 7 of every byte of the word that belongs to the segment
+                const uint32_t x = w[j], y = ~x;
+                const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+                const uint32_t f = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu) & inm;
+                const uint32_t before = __builtin_amdgcn_alignbyte(f, fprev, 3);
+                kill[j] = (z & before) | (inm ^ 0x80808080u);
+                ndrop += __popc(kill[j]);
+                fprev = f;
+            }
+            n = (uint32_t)NB - ndrop;
+        } else {
+            n = 0;
         }
-        n = (uint32_t)NB - ndrop;
-    } else if (!wave_empty) {
-        // first and last tile of a segment: the same word-parallel tests, with the bytes outside [lo, hi)
-        // masked -- they are not kept, and an FF among them is not "the byte before"
-        uint32_t fprev = pf ? 0x80000000u : 0u, ndrop = 0;
+        if (!SINGLE && t == 0) s_tile = next_ticket;
+        uint32_t total;
+        const uint32_t inc = block_incl_scan<ZJ_K0_THREADS / 64>(n, wsum, &total); // its barriers also end the reads of the raw tile
+        // the tile's own count goes out first, so that the tiles behind it can already add it up
+        if (!SINGLE && t == 0 && tj > 0) __hip_atomic_store(&P.tile_status[tile], ZJ_TS_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!wave_empty) {
+            // Compaction in LDS, from byte ZJ_K0_PAD on, before the tile's place in the segment is known (the
+            // wait for the predecessors is hidden behind it).  Every byte is stored at the position of the next
+            // kept byte: a byte that is not kept is overwritten by the kept byte that follows it in the same
+            // thread (LDS stores of a lane are executed in order); only a thread's last byte has no successor
+            // and goes to a spare slot.
+            uint32_t o = ZJ_K0_PAD + inc - n;
 #pragma unroll
-        for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) {
-            const int32_t lj = (int32_t)lo - (int32_t)(4u * j), hj = (int32_t)hi - (int32_t)(4u * j);
-            const uint32_t l4 = lj <= 0 ? 0u : (lj >= 4 ? 4u : (uint32_t)lj), h4 = hj <= 0 ? 0u : (hj >= 4 ? 4u : (uint32_t)hj);
-            const uint32_t ge = (uint32_t)(0x80808080ull << (8u * l4)), lt = 0x80808080u & ~(uint32_t)(0x80808080ull << (8u * h4));
-            const uint32_t inm = ge & lt; // bit 7 of every byte of the word that belongs to the segment
-            const uint32_t x = w[j], y = ~x;
-            const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
-            const uint32_t f = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu) & inm;
-            const uint32_t before = __builtin_amdgcn_alignbyte(f, fprev, 3);
-            kill[j] = (z & before) | (inm ^ 0x80808080u);
-            ndrop += __popc(kill[j]);
-            fprev = f;
-        }
-        n = (uint32_t)NB - ndrop;
-    } else {
-        n = 0;
-    }
-    uint32_t total;
-    const uint32_t inc = block_incl_scan<ZJ_K0_THREADS / 64>(n, wsum, &total); // its barriers also end the reads of the raw tile
-    // the tile's own count goes out first, so that the tiles behind it can already add it up
-    if (!SINGLE && tid == 0 && tj > 0) __hip_atomic_store(&P.tile_status[tile], ZJ_TS_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!wave_empty) {
-        // Compaction in LDS, from byte ZJ_K0_PAD on, before the tile's place in the segment is known (the
-        // wait for the predecessors is hidden behind it).  Every byte is stored at the position of the next
-        // kept byte: a byte that is not kept is overwritten by the kept byte that follows it in the same
-        // thread (LDS stores of a lane are executed in order); only a thread's last byte has no successor
-        // and goes to a spare slot.
-        uint32_t o = ZJ_K0_PAD + inc - n;
+            for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) {
 #pragma unroll
-        for (uint32_t j = 0; j < ZJ_K0_WORDS; j++) {
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; k++) {
-                const uint32_t dead = (kill[j] >> (8u * k + 7u)) & 1u;
-                const uint32_t at = (j == ZJ_K0_WORDS - 1u && k == 3u && dead) ? ZJ_K0_TILE + ZJ_K0_PAD + 48u : o;
-                buf[at] = (uint8_t)(w[j] >> (8u * k));
-                o += 1u - dead;
+                for (uint32_t k = 0; k < 4u; k++) {
+                    const uint32_t dead = (kill[j] >> (8u * k + 7u)) & 1u;
+                    const uint32_t at = (j == ZJ_K0_WORDS - 1u && k == 3u && dead) ? ZJ_K0_TILE + ZJ_K0_PAD + 48u : o;
+                    buf[at] = (uint8_t)(w[j] >> (8u * k));
+                    o += 1u - dead;
+                }
             }
         }
-    }
-    if (SINGLE) {
-        if (tid == 0) { s_prefix = 0; P.seg_payload_bits[s] = total * 8u; }
-    } else if (tid < 64u) {
-        // look-back by the first wavefront: 64 predecessors per step.  The nearest tile that has published
-        // an inclusive prefix ends the walk; every tile between it and this one must at least have
-        // published its own count, otherwise the step is repeated.
-        uint32_t excl = 0;
-        if (tj > 0) {
-            int64_t base = (int64_t)tile - 1;
-            for (;;) {
-                const int64_t j = base - (int64_t)tid;
-                uint64_t sv = ZJ_TS_INCL; // in front of the segment's first tile: nothing, and final
-                if (j >= (int64_t)sg.first_tile) sv = __hip_atomic_load(&P.tile_status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t flag = (uint32_t)(sv >> 32);
-                const uint64_t incl = __ballot(flag == 2u), pending = __ballot(flag == 0u);
-                const uint32_t first = incl ? (uint32_t)__builtin_ctzll(incl) : 64u;
-                const uint64_t needed = first >= 63u ? ~0ull : ((2ull << first) - 1ull); // lanes 0..first
-                if (pending & needed) { __builtin_amdgcn_s_sleep(8); continue; }
-                uint32_t v = (tid <= first) ? (uint32_t)sv : 0u;
+        // the next tile's bytes are asked for now: the registers of the byte tests are free again, and the look-back and the
+        // copy below cover the trip
+        uint32_t tn = 0;
+        bool more = false;
+        asm volatile("" ::: "memory"); // not earlier: the loads' registers would overlap those of the byte tests
+        __builtin_amdgcn_sched_barrier(0);
+        if (!SINGLE) {
+            tn = s_tile;
+            more = tn < sg.ntiles; // uniform
+            if (more) request(tn);
+            else {
+                pfb = 0; // (defined on every path, like w and kill above)
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-                excl += v;
-                if (first < 64u) break;
-                base -= 64;
+                for (uint32_t i = 0; i < NLD; i++) ld[i] = make_uint4(0, 0, 0, 0);
             }
         }
-        if (tid == 0) {
-            __hip_atomic_store(&P.tile_status[tile], ZJ_TS_INCL | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_prefix = excl;
-            if (tile + 1u == sg.first_tile + sg.ntiles) P.seg_payload_bits[s] = (excl + total) * 8u;
-        }
-    }
-    __syncthreads();
-    // Copy out in 16-byte pieces aligned in global memory.  In piece coordinates (byte 0 = the aligned
-    // address at or below the tile's first output byte) the tile owns [shift, shift + total); coordinate c
-    // is LDS byte ZJ_K0_PAD + c - shift, so a piece is 16 bytes at one fixed misalignment for the whole
-    // tile: two aligned 16-byte LDS reads and a byte funnel shift.
-    const uint32_t prefix = s_prefix;
-    const uint32_t shift = prefix & 15u;
-    uint8_t *out = P.ust + sg.out_off + (prefix - shift);
-    const uint32_t endpos = shift + total;
-    const uint32_t mis = (uint32_t)__builtin_amdgcn_readfirstlane((int)((ZJ_K0_PAD - shift) & 15u)); // LDS misalignment of a piece
-    const uint32_t wo = mis >> 2, bs = mis & 3u;
-    for (uint32_t pc = tid; pc * 16u < endpos; pc += ZJ_K0_THREADS) {
-        const uint32_t b0 = pc * 16u;
-        const uint32_t src = ZJ_K0_PAD + b0 - shift; // >= 1
-        if (b0 >= shift && b0 + 16u <= endpos) {
-            const uint4 lo = *reinterpret_cast<const uint4 *>(buf + (src & ~15u));
-            const uint4 hi = *reinterpret_cast<const uint4 *>(buf + (src & ~15u) + 16u);
-            uint32_t a0, a1, a2, a3, a4;
-            switch (wo) { // uniform
-            case 0: a0 = lo.x; a1 = lo.y; a2 = lo.z; a3 = lo.w; a4 = hi.x; break;
-            case 1: a0 = lo.y; a1 = lo.z; a2 = lo.w; a3 = hi.x; a4 = hi.y; break;
-            case 2: a0 = lo.z; a1 = lo.w; a2 = hi.x; a3 = hi.y; a4 = hi.z; break;
-            default: a0 = lo.w; a1 = hi.x; a2 = hi.y; a3 = hi.z; a4 = hi.w; break;
+        if (SINGLE) {
+            if (t == 0) { s_prefix = 0; P.seg_payload_bits[s] = total * 8u; }
+        } else if (t < 64u) {
+            // look-back by the first wavefront: 64 predecessors per step.  The nearest tile that has published
+            // an inclusive prefix ends the walk; every tile between it and this one must at least have
+            // published its own count, otherwise the step is repeated.
+            uint32_t excl = 0;
+            if (tj > 0) {
+                int64_t base = (int64_t)tile - 1;
+                for (;;) {
+                    const int64_t j = base - (int64_t)t;
+                    uint64_t sv = ZJ_TS_INCL; // in front of the segment's first tile: nothing, and final
+                    if (j >= (int64_t)sg.first_tile) sv = __hip_atomic_load(&P.tile_status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t flag = (uint32_t)(sv >> 32);
+                    const uint64_t incl = __ballot(flag == 2u), pending = __ballot(flag == 0u);
+                    const uint32_t first = incl ? (uint32_t)__builtin_ctzll(incl) : 64u;
+                    const uint64_t needed = first >= 63u ? ~0ull : ((2ull << first) - 1ull); // lanes 0..first
+                    if (pending & needed) { __builtin_amdgcn_s_sleep(8); continue; }
+                    uint32_t v = (t <= first) ? (uint32_t)sv : 0u;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                    excl += v;
+                    if (first < 64u) break;
+                    base -= 64;
+                }
             }
-            *reinterpret_cast<uint4 *>(out + b0) = make_uint4(__builtin_amdgcn_alignbyte(a1, a0, bs), __builtin_amdgcn_alignbyte(a2, a1, bs),
-                                                              __builtin_amdgcn_alignbyte(a3, a2, bs), __builtin_amdgcn_alignbyte(a4, a3, bs));
-        } else { // a piece shared with the neighbouring tile: only this tile's bytes
-            for (uint32_t k = 0; k < 16u; k++)
-                if (b0 + k >= shift && b0 + k < endpos) out[b0 + k] = buf[src + k];
+            if (t == 0) {
+                __hip_atomic_store(&P.tile_status[tile], ZJ_TS_INCL | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_prefix = excl;
+                if (tile + 1u == sg.first_tile + sg.ntiles) P.seg_payload_bits[s] = (excl + total) * 8u;
+            }
         }
-    }
-    // The segment's last tile clears the reserved bytes behind the payload: the readers run up to 96 bytes
-    // past it and must find zeros there (src/bitstream.rs:80-84), whatever the arena held before.
-    if (SINGLE || tile + 1u == sg.first_tile + sg.ntiles) {
-        uint8_t *seg_out = P.ust + sg.out_off;
-        for (uint32_t i = prefix + total + tid; i < sg.out_cap; i += ZJ_K0_THREADS) seg_out[i] = 0;
+        __syncthreads();
+        // Copy out in 16-byte pieces aligned in global memory.  In piece coordinates (byte 0 = the aligned
+        // address at or below the tile's first output byte) the tile owns [shift, shift + total); coordinate c
+        // is LDS byte ZJ_K0_PAD + c - shift, so a piece is 16 bytes at one fixed misalignment for the whole
+        // tile: two aligned 16-byte LDS reads and a byte funnel shift.
+        const uint32_t prefix = s_prefix;
+        const uint32_t shift = prefix & 15u;
+        uint8_t *out = P.ust + sg.out_off + (prefix - shift);
+        const uint32_t endpos = shift + total;
+        const uint32_t mis = (uint32_t)__builtin_amdgcn_readfirstlane((int)((ZJ_K0_PAD - shift) & 15u)); // LDS misalignment of a piece
+        const uint32_t wo = mis >> 2, bs = mis & 3u;
+        for (uint32_t pc = t; pc * 16u < endpos; pc += ZJ_K0_THREADS) {
+            const uint32_t b0 = pc * 16u;
+            const uint32_t src = ZJ_K0_PAD + b0 - shift; // >= 1
+            if (b0 >= shift && b0 + 16u <= endpos) {
+                const uint4 lo = *reinterpret_cast<const uint4 *>(buf + (src & ~15u));
+                const uint4 hi = *reinterpret_cast<const uint4 *>(buf + (src & ~15u) + 16u);
+                uint32_t a0, a1, a2, a3, a4;
+                switch (wo) { // uniform
+                case 0: a0 = lo.x; a1 = lo.y; a2 = lo.z; a3 = lo.w; a4 = hi.x; break;
+                case 1: a0 = lo.y; a1 = lo.z; a2 = lo.w; a3 = hi.x; a4 = hi.y; break;
+                case 2: a0 = lo.z; a1 = lo.w; a2 = hi.x; a3 = hi.y; a4 = hi.z; break;
+                default: a0 = lo.w; a1 = hi.x; a2 = hi.y; a3 = hi.z; a4 = hi.w; break;
+                }
+                *reinterpret_cast<uint4 *>(out + b0) = make_uint4(__builtin_amdgcn_alignbyte(a1, a0, bs), __builtin_amdgcn_alignbyte(a2, a1, bs),
+                                                                  __builtin_amdgcn_alignbyte(a3, a2, bs), __builtin_amdgcn_alignbyte(a4, a3, bs));
+            } else { // a piece shared with the neighbouring tile: only this tile's bytes
+                for (uint32_t k = 0; k < 16u; k++)
+                    if (b0 + k >= shift && b0 + k < endpos) out[b0 + k] = buf[src + k];
+            }
+        }
+        // The segment's last tile clears the reserved bytes behind the payload: the readers run up to 96 bytes
+        // past it and must find zeros there (src/bitstream.rs:80-84), whatever the arena held before.
+        if (SINGLE || tile + 1u == sg.first_tile + sg.ntiles) {
+            uint8_t *seg_out = P.ust + sg.out_off;
+            for (uint32_t i = prefix + total + t; i < sg.out_cap; i += ZJ_K0_THREADS) seg_out[i] = 0;
+        }
+
+        if (SINGLE || !more) break;
+        tj = tn;
+        __syncthreads(); // the buffer is free for the next tile
     }
 }
 

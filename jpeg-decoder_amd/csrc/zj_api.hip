@@ -465,6 +465,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     b->imgs.resize(n);
     b->unsupported.assign(n, 0);
     std::vector<uint32_t> chunk_seg, blk256_img, k1w_img, ptile_seg, tile_seg, small_seg, dtile_seg, dsmall_seg;
+    uint64_t dc_longest = 0;  // MCUs of the longest segment
     size_t unstuff_tiles = 0; // tiles of the unstuff pass's 128-thread form over all segments: one look-back word each
     uint64_t nwin_total = 0;
     std::vector<uint32_t> k2_grp[ZJ_K2_CLASSES], k2_img[ZJ_K2_CLASSES]; // stage-2 workgroups per sampling layout
@@ -722,6 +723,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
             } else {
                 s.first_dtile = (uint32_t)dtile_seg.size();
                 s.ndtiles = (uint32_t)((mc + 255u) / 256u);
+                dc_longest = std::max<uint64_t>(dc_longest, mc);
                 if (s.ndtiles > 1u) b->L.ndmulti++;
                 for (uint32_t t = 0; t < s.ndtiles; t++) dtile_seg.push_back((uint32_t)b->segs.size());
             }
@@ -922,9 +924,9 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     b->L.ndsmall = (uint32_t)dsmall_seg.size();
     {
         // the DC scan by whole segments pays when the segments fill the GPU on their own and are long enough to occupy a
-        // workgroup of 1024 lanes; one huge segment, or many short ones, are better off in tiles
+        // workgroup of 1024 lanes; huge segments, or many short ones, are better off in tiles
         const size_t nlong = b->segs.size() - dsmall_seg.size();
-        b->L.dc_by_segment = nlong >= 256u && nbigd >= nlong * 8u && nbigd <= nlong * 256u;
+        b->L.dc_by_segment = nlong >= 256u && nbigd >= nlong * 8u && dc_longest <= 16384u; // (a longer segment is a chain of more than four steps of one workgroup)
     }
     b->L.nstrips = (uint32_t)strip_grp_all.size();
     b->L.fix_iters = 1;

@@ -786,9 +786,9 @@ __global__ __launch_bounds__(256) void zj_k1s_scan(ZjParams P)
     const uint32_t *rec = P.winfo + sg.first_win;
     uint32_t *wb = P.wbase + sg.first_win;
     uint32_t carry = sg.blk_bias;
-    if (sg.lanes == 64u && sg.nsub <= 128u) {
-        // One or two whole chunks of 64 subsequences (a longer segment is a longer
-        // chain of tiles than of the plain steps below): the records lie [chunk][window of
+    if (sg.lanes == 64u && NC >= 32u) {
+        // Whole chunks of 64 subsequences of many windows each (with few windows per subsequence the plain steps below
+        // are the shorter chain): the records lie [chunk][window of
         // the subsequence][lane] while the result goes out in stream order [lane][window], so a chunk is taken in
         // tiles of 64 windows x 64 lanes through LDS, with the reads and the writes both along their own layout.
         __shared__ uint32_t tl[64 * 65];

@@ -148,7 +148,8 @@ const char *zj_last_error(zj_ctx *ctx);
 
 /* Plan a batch: validates the images, builds the device tables, uploads the scans, allocates all
  * scratch and the coefficient arena.  Everything the decode call needs is resident in HBM when
- * this returns.  Images that are unsupported keep a slot and report ZJ_ST_UNSUPPORTED. */
+ * this returns.  Images that are unsupported keep a slot and report ZJ_ST_UNSUPPORTED.  A scan of
+ * 0xF0000000 bytes or more is refused (ZJ_E_INVALID): positions inside a scan are 32-bit. */
 zj_batch *zj_batch_create(zj_ctx *ctx, const zj_image *imgs, size_t n, uint32_t flags);
 void zj_batch_destroy(zj_batch *b);
 

@@ -255,7 +255,10 @@ int zj_batch_finish(zj_batch *b, uint32_t *status);
  * All three are 0 for every stream seen so far; waits for the stream. */
 int zj_batch_counters(zj_batch *b, uint32_t counters[3]);
 
-/* Device pointer to image i's quantised coefficients inside the arena (valid until destroy). */
+/* Device pointer to image i's quantised coefficients inside the arena (valid until destroy).  The decode call keeps
+ * the DC values in an array of their own (the arena's coefficient 0 holds the DC difference of src/decoder.rs:198 until
+ * someone asks): the first call after a decode call queues one small kernel on the context's stream that writes them
+ * into the arena; what the pointer shows is complete once that stream has been waited for. */
 const int16_t *zj_batch_qcoef(zj_batch *b, size_t i);
 /* Copy image i's coefficients out: zig-zag quantised and/or natural-order dequantised. */
 int zj_batch_export_coef(zj_batch *b, size_t i, int16_t *qcoef, int16_t *dqcoef, int mem);

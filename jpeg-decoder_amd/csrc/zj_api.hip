@@ -108,6 +108,7 @@ struct zj_batch {
     // another stream; created on first use of such a stream
     hipEvent_t entropy_done, pixels_done;
     bool entropy_launched;
+    bool dc_patched; // coefficient 0 of the arena's blocks has been filled in from the DC array since the last decode call
     bool split_ev_valid, pixels_pending; // pixels_pending: pixels_done was recorded on a stream other than the context's
     uint32_t slow_path_calls; // zj_batch_finish calls that had to run the exhaustive fix-up loop
     uint64_t scan_bytes, coef_bytes, rgb_bytes, pixels;
@@ -412,7 +413,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     b->ev_valid = false; b->profiling = false; b->decoded = false;
     b->ready_valid = false; b->ready_waited = false; b->tables_ev_valid = false; b->tables_ev_pending = false;
     b->slow_path_calls = 0;
-    b->entropy_launched = false; b->split_ev_valid = false; b->pixels_pending = false;
+    b->entropy_launched = false; b->split_ev_valid = false; b->pixels_pending = false; b->dc_patched = false;
     b->scan_bytes = b->coef_bytes = b->rgb_bytes = b->pixels = 0;
     memset(&b->range, 0, sizeof b->range);
     b->ws = nullptr;
@@ -531,6 +532,7 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
     k2_ns = ZJ_K2_NS_FORCE;
 #endif
     b->P.k2_ns = k2_ns;
+    b->P.dc_in_write = (win_row0 == nullptr && seg_range == nullptr) ? 1u : 0u; // (a window of rows or a part of a stream: the DC pass of its own)
     for (size_t i = 0; i < n; i++) {
         const zj_image &im = images[i];
         ZjImgDev &d = b->imgs[i];
@@ -817,6 +819,16 @@ static zj_batch *batch_create_impl(zj_ctx *ctx, const zj_image *images, size_t n
             wt_info[set * 2u + t] = ZJ_WT_TWO_LEVEL;
             for (uint32_t e = 0; e < ZJ_TBL_ENTRIES; e++) wt[e] = zj_write_entry(luts[set * ZJ_SET_ENTRIES + (2u + t) * ZJ_TBL_ENTRIES + e]);
         }
+    // behind the entries of AC table t: the first level of DC table t, one byte per entry (zj_core.h, ZJ_WT_DIRECT)
+    for (size_t set = 0; set < nsets; set++)
+        for (uint32_t t = 0; t < 2u; t++) {
+            uint8_t *dc8 = reinterpret_cast<uint8_t *>(&wtabs[(set * 2u + t) * ZJ_WT_ENTRIES + ZJ_WT_DIRECT]);
+            for (uint32_t i = 0; i < ZJ_L1_SIZE; i++) {
+                const uint32_t e = luts[set * ZJ_SET_ENTRIES + t * ZJ_TBL_ENTRIES + i];
+                const uint32_t len = (e >> 8) & 31u, sz = e & 255u;
+                dc8[i] = ((e & 0x8000u) || len == 0 || len > 15u || sz > 15u) ? 0u : (uint8_t)(len | (sz << 4));
+            }
+        }
     P.luts = dev_upload(b, luts);
     P.wluts = dev_upload(b, wluts);
     P.ptabs = dev_upload(b, ptabs);
@@ -1070,6 +1082,7 @@ static int decode_entropy(zj_batch *b)
         b->ready_waited = true;
     }
     b->entropy_launched = true;
+    b->dc_patched = false;
     if (b->L.nchunks == 0) { // nothing to decode: the status words are all this call has to clear (otherwise stage 1's one fill does)
         if (b->n && !hip_ok(c, hipMemsetAsync(b->P.status, 0, b->n * sizeof(uint32_t), st), "memset status")) return ZJ_E_DEVICE;
         return ZJ_OK;
@@ -1257,9 +1270,23 @@ extern "C" int zj_batch_counters(zj_batch *b, uint32_t *counters)
     return ZJ_OK;
 }
 
+// The write pass leaves the DC difference in coefficient 0 of every block and the IDCT/colour kernel takes the value from
+// the DC array; a caller that wants the arena itself gets the values written into it first (once per decode call).
+static bool ensure_dc_patched(zj_batch *b)
+{
+    if (b->dc_patched || !b->entropy_launched || b->L.nchunks == 0) return true;
+    zj_ctx *c = b->ctx;
+    if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return false;
+    zj_launch_patch_dc(b->P, b->L.nblk256 * 256u, c->stream);
+    if (!hip_ok(c, hipGetLastError(), "DC patch launch")) return false;
+    b->dc_patched = true;
+    return true;
+}
+
 extern "C" const int16_t *zj_batch_qcoef(zj_batch *b, size_t i)
 {
     if (!b || i >= b->n || b->unsupported[i]) return nullptr;
+    if (!ensure_dc_patched(b)) return nullptr;
     return b->P.qcoef + (size_t)b->imgs[i].first_block * 64;
 }
 
@@ -1269,6 +1296,7 @@ extern "C" int zj_batch_export_coef(zj_batch *b, size_t i, int16_t *qcoef, int16
     zj_ctx *c = b->ctx;
     if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return ZJ_E_DEVICE;
     hipStream_t st = c->stream;
+    if (!ensure_dc_patched(b)) return ZJ_E_DEVICE;
     const size_t bytes = (size_t)b->imgs[i].nblocks * 128;
     const hipMemcpyKind kind = mem == ZJ_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (qcoef && !hip_ok(c, hipMemcpyAsync(qcoef, zj_batch_qcoef(b, i), bytes, kind, st), "copy qcoef")) return ZJ_E_DEVICE;
@@ -1328,6 +1356,7 @@ extern "C" int zj_batch_kernel_times(zj_batch *b, float *ms)
     if (!hip_ok(c, hipEventSynchronize(b->ev[8]), "event sync")) return ZJ_E_DEVICE;
     for (int k = 0; k < 8; k++)
         if (!hip_ok(c, hipEventElapsedTime(&ms[k], b->ev[k], b->ev[k + 1]), "event elapsed")) return ZJ_E_DEVICE;
+    if (b->P.dc_in_write) std::swap(ms[5], ms[6]); // the write pass came before the DC scan: the names follow the other order
     if (!hip_ok(c, hipEventElapsedTime(&ms[8], b->ev[0], b->ev[8]), "event elapsed")) return ZJ_E_DEVICE;
     return ZJ_OK;
 }
@@ -1623,6 +1652,7 @@ extern "C" int zj_batch_range_decode(zj_batch *b, uint8_t *rgb, size_t stride)
     }
     if (!hip_ok(c, hipGetLastError(), "kernel launch")) return ZJ_E_DEVICE;
     b->entropy_launched = true;
+    b->dc_patched = false;
     uint8_t *r1[1] = {b->imgs[0].nrows ? rgb : nullptr};
     size_t s1[1] = {stride};
     return decode_pixels(b, r1, s1, c->stream);

@@ -77,9 +77,12 @@
 // t16 = the first code longer than ZJ_L1_BITS bits, left-aligned in 16 bits (a multiple of 128; 0x10000 when there is
 // none), the entry for the next 16 bits x of the stream is at index (x >> 7) + max(0, x - t16) -- the first level for
 // x < t16, and behind it one entry per 16-bit value, which begins in the first-level slots of the long prefixes.  The
-// form is used when 512 + 0x10000 - t16 <= ZJ_WT_ENTRIES (the Annex K tables need 1152 entries); otherwise the write
+// form is used when 512 + 0x10000 - t16 <= ZJ_WT_DIRECT (the Annex K tables need 1152 entries); otherwise the write
 // entries stay in the two-level layout (ZJ_WT_TWO_LEVEL in place of t16).
 #define ZJ_WT_ENTRIES 1280
+// Of those, the direct form may use the first ZJ_WT_DIRECT; the 128 words behind them hold the first level of a DC table,
+// one byte per entry: code length | size << 4, or 0 for "consult the 16-bit table" (a longer code, no code, a size over 15).
+#define ZJ_WT_DIRECT 1152
 #define ZJ_WT_TWO_LEVEL 0xFFFFFFFFu
 
 // Canonical description of one table, used by the rare fallback path only.

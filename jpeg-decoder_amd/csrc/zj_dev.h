@@ -36,7 +36,7 @@ struct ZjParams {
     uint64_t *tile_status;      // [unstuff tile] look-back word: flag << 32 | bytes
     uint32_t *seg_ticket;       // [segment] next tile of the segment to hand out (stored behind tile_status)
     uint32_t *blockpos;         // [block] bit position of the block in its segment's stream
-    int16_t *dcabs;             // [block] DC value after prediction
+    int16_t *dcabs;             // [block] DC value after prediction (before the DC scan: the difference)
     uint8_t *dcbits;            // [block] bits of the DC symbol and its value (ZJ_DC_BAD: no code)
     int16_t *qcoef;             // [block][64] zig-zag, quantised: the stage seam
     const uint16_t *luts;       // [table set][ZJ_SET_ENTRIES]
@@ -59,6 +59,7 @@ struct ZjParams {
     uint32_t nchunks;
     uint32_t nseg;
     uint32_t k2_ns;             // strips per workgroup of the IDCT/colour kernel
+    uint32_t dc_in_write;       // the write pass stores the DC differences it decodes and the DC scan follows it (0: a pass of its own and the scan come first)
 };
 
 #define ZJ_K2_NS 4 // strips per workgroup of the IDCT/colour kernel at least; the planner doubles it up to 16 in large batches (ZjParams::k2_ns)
@@ -115,4 +116,5 @@ void zj_launch_range_sync(const ZjParams &P, const ZjLaunch &L, hipStream_t st);
 void zj_launch_range_dc(const ZjParams &P, const ZjLaunch &L, hipStream_t st);
 void zj_launch_range_write(const ZjParams &P, const ZjLaunch &L, hipStream_t st, uint32_t g0, uint32_t g1, const uint32_t *off);
 void zj_launch_dequant(const ZjParams &P, uint32_t ii, uint32_t nblocks, int16_t *dst, hipStream_t st);
+void zj_launch_patch_dc(const ZjParams &P, uint32_t nblocks, hipStream_t st);
 }

@@ -310,16 +310,16 @@ bool zj_build_table(const zj_huff *h, uint16_t *tbl, ZjCanon *canon, uint32_t l2
     return true;
 }
 
-// Write entries of an AC table in the direct form (zj_core.h, ZJ_WT_ENTRIES): returns false when the codes longer than
+// Write entries of an AC table in the direct form (zj_core.h, ZJ_WT_DIRECT): returns false when the codes longer than
 // the first level take more room than the form has, and the caller keeps the two-level layout.
 bool zj_build_direct_table(const ZjCanon *canon, uint32_t *wt, uint32_t *t16)
 {
     uint32_t first_long = 0x10000u;
     for (uint32_t l = ZJ_L1_BITS + 1; l <= 16 && first_long == 0x10000u; l++)
         if (canon->ncode[l]) first_long = (uint32_t)canon->mincode[l] << (16 - l);
-    if (first_long != 0x10000u && ((first_long & 127u) != 0 || (0xFFFFu >> 7) + (0xFFFFu - first_long) >= ZJ_WT_ENTRIES)) return false;
+    if (first_long != 0x10000u && ((first_long & 127u) != 0 || (0xFFFFu >> 7) + (0xFFFFu - first_long) >= ZJ_WT_DIRECT)) return false;
     const uint32_t none = zj_write_entry(0);
-    for (uint32_t i = 0; i < ZJ_WT_ENTRIES; i++) wt[i] = none;
+    for (uint32_t i = 0; i < ZJ_WT_DIRECT; i++) wt[i] = none;
     for (uint32_t l = 1; l <= 16; l++) {
         for (uint32_t i = 0; i < canon->ncode[l]; i++) {
             const uint32_t code = (uint32_t)canon->mincode[l] + i, sym = canon->symbols[(canon->valptr[l] + i) & 255u];

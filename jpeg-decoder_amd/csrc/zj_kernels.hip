@@ -1421,7 +1421,7 @@ __device__ __forceinline__ void zj_k1w_symbols_ref(uint32_t &w0, uint32_t &w1, u
 
 __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lut[ZJ_WT_ENTRIES]; // write entries of this workgroup's AC table
+    __shared__ __attribute__((aligned(16))) uint32_t lut[ZJ_WT_ENTRIES]; // write entries of this workgroup's AC table; behind them (ZJ_WT_DIRECT) the first level of its DC table, a byte per entry
     __shared__ uint32_t tile[4][64 * 33];
     __shared__ uint32_t scol[4][ZJ_K1W_SLOTS * 64];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -1458,11 +1458,18 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
         const uint32_t tac0 = (im.acsel >> (luma ? 0u : nl)) & 1u;          // the AC table of these blocks
         const bool mixed = !luma && ((im.acsel >> (nl + 1u)) & 1u) != tac0; // Cb and Cr with different AC tables
         const uint32_t t16 = P.wt_info[im.lut_set * 2u + tac0]; // ZJ_WT_TWO_LEVEL, or the parameter of the direct form
-        if (luma || tac0 != (im.acsel & 1u)) { // uniform: the chroma blocks may use the luma table
-            if (phase) __syncthreads(); // every wavefront is done with the luma table
-            const uint4 *s4 = reinterpret_cast<const uint4 *>(P.wtabs + (size_t)(im.lut_set * 2u + tac0) * ZJ_WT_ENTRIES);
-            uint4 *d4 = reinterpret_cast<uint4 *>(lut);
-            for (uint32_t i = threadIdx.x; i < ZJ_WT_ENTRIES * 4u / 16u; i += 256u) d4[i] = s4[i];
+        const uint32_t tdc0 = (im.dcsel >> (luma ? 0u : nl)) & 1u;          // the DC table of these blocks (of Cb in the chroma phase)
+        const bool new_ac = luma || tac0 != (im.acsel & 1u), new_dc = luma || tdc0 != (im.dcsel & 1u); // uniform: the chroma blocks may use the luma tables
+        if (new_ac || new_dc) {
+            if (phase) __syncthreads(); // every wavefront is done with the luma tables
+            if (new_ac) {
+                const uint4 *s4 = reinterpret_cast<const uint4 *>(P.wtabs + (size_t)(im.lut_set * 2u + tac0) * ZJ_WT_ENTRIES);
+                uint4 *d4 = reinterpret_cast<uint4 *>(lut);
+                for (uint32_t i = threadIdx.x; i < ZJ_WT_DIRECT * 4u / 16u; i += 256u) d4[i] = s4[i];
+            }
+            if (new_dc && threadIdx.x < (ZJ_WT_ENTRIES - ZJ_WT_DIRECT) * 4u / 16u)
+                reinterpret_cast<uint4 *>(lut + ZJ_WT_DIRECT)[threadIdx.x] =
+                    reinterpret_cast<const uint4 *>(P.wtabs + (size_t)(im.lut_set * 2u + tdc0) * ZJ_WT_ENTRIES + ZJ_WT_DIRECT)[threadIdx.x];
             __syncthreads();
         }
         // the table sets whose long codes need the canonical search, and rounds whose lanes use two tables, take the
@@ -1479,15 +1486,14 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
         // return is only looked at through have / has_next in the round that uses it: a load under a
         // condition, or a value converted on the spot, would make the wavefront wait for memory right here.
         struct Desc {
-            uint32_t p0, pnext, pay, kb, dcbits;
-            uint32_t dc; // the DC value's 16 bits
+            uint32_t p0, pnext, pay, kb;
+            uint32_t g; // the block's index in the batch's arrays
             const uint32_t *stream;
             bool valid, have, has_next; // the block exists / its position is known / so is the next block's
         };
         auto describe = [&](uint32_t r) -> Desc {
             Desc d;
-            d.valid = false; d.have = false; d.has_next = false; d.p0 = 0; d.pnext = 0; d.pay = 0; d.kb = 0; d.stream = nullptr; d.dc = 0;
-            d.dcbits = 0;
+            d.valid = false; d.have = false; d.has_next = false; d.p0 = 0; d.pnext = 0; d.pay = 0; d.kb = 0; d.stream = nullptr; d.g = 0;
             if (r >= rounds) return d; // uniform
             const uint32_t qi = r * 64u + lane;
             const uint32_t mcu = m0 + (qi >> sh);
@@ -1509,9 +1515,8 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
             d.have = d.valid && gs < fnd;
             d.has_next = d.have && gs + 1u < fnd;
             const uint32_t gi = d.have ? g : im.first_block;
+            d.g = g;
             d.p0 = P.blockpos[gi];
-            d.dc = (uint16_t)P.dcabs[gi];
-            d.dcbits = P.dcbits[gi];
             d.pnext = P.blockpos[d.has_next ? g + 1u : gi];
             return d;
         };
@@ -1560,12 +1565,33 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
             const Desc nn = describe(r + 2u);
 
             // ---- this round's block (src/decoder.rs:186-235; the DC value comes from the prefix scan)
-            const uint32_t dcb = cur.have ? cur.dcbits : ZJ_DC_BAD;
+            // The DC symbol (src/decoder.rs:194-199 without the predictor): its bits are the first of the staged column.  The
+            // difference goes to the DC array, which the scan behind this pass turns into values; coefficient 0 of the
+            // arena keeps the difference, and whoever reads the arena takes the value from the DC array.
+            uint32_t dcb = ZJ_DC_BAD;
+            int32_t dcdiff = 0;
+            if (cur.have) {
+                const uint64_t two = ((uint64_t)col[0] << 32) | col[64];
+                const uint32_t top = (uint32_t)((two << (cur.p0 & 31u)) >> 32);
+                const uint32_t tdc = (im.dcsel >> cur.kb) & 1u;
+                const uint32_t e8 = reinterpret_cast<const uint8_t *>(lut + ZJ_WT_DIRECT)[top >> (32 - ZJ_L1_BITS)];
+                uint32_t len = e8 & 15u, sz = e8 >> 4;
+                if (tdc != tdc0 || e8 == 0u) { // Cr with a DC table of its own, or not a short code: the tables in memory
+                    const uint32_t en = zj_lookup(P.luts + (size_t)im.lut_set * ZJ_SET_ENTRIES + tdc * ZJ_TBL_ENTRIES, P.canons + (size_t)im.lut_set * 4u + tdc, top);
+                    len = (en >> 8) & 31u;
+                    sz = en & 255u;
+                }
+                if (len != 0u && sz <= 16u) {
+                    dcb = len + sz;
+                    dcdiff = zj_extend(sz, sz ? ((top << len) >> (32u - sz)) : 0u);
+                }
+            }
+            if (P.dc_in_write && cur.valid) P.dcabs[cur.g] = (int16_t)dcdiff;
             const uint32_t pnext = cur.has_next ? cur.pnext : 0xFFFFFFFFu;
             uint32_t p = cur.p0 + dcb, z = 1, e = ZJ_WE_START; // p >= 1: a DC symbol has at least one bit
             bool live = cur.valid && dcb != ZJ_DC_BAD;            // still has symbols to decode
             if (cur.valid && !live) status |= cur.have ? 1u : 4u; // no DC code / no position: bad code / truncated
-            if (live) row[0] = (int16_t)cur.dc;
+            if (live) row[0] = (int16_t)dcdiff;
             uint32_t wa = cur.p0 >> 5; // stream word held in slot 0 of the column
             const uint32_t tac = (im.acsel >> cur.kb) & 1u;
             for (;;) {
@@ -1611,7 +1637,7 @@ __global__ __launch_bounds__(256) void zj_k1w_write(ZjParams P)
             // Pin the rotation here, where the loads of this round's description are long complete and no store is
             // in flight: left to itself the compiler copies the registers at the loop's back edge, behind the
             // stores below, and has to wait there for every outstanding memory operation, stores included.
-            asm volatile("" : "+v"(nxt.p0), "+v"(nxt.pnext), "+v"(nxt.dcbits), "+v"(nxt.dc));
+            asm volatile("" : "+v"(nxt.p0), "+v"(nxt.pnext), "+v"(nxt.g));
             // the column is free: the next round's bits go in, and the head registers take the bits after those
             stage(hd);
             fetch_head(nxt, hd);
@@ -1824,27 +1850,45 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
     // quantisation values of this lane's eighth, per component, two 16-bit values per word
     const uint4 *qpart = reinterpret_cast<const uint4 *>(qlds) + part;
 
-    auto strip_src = [&](uint32_t strip, uint32_t &nbw) -> const int16_t * {
+    // first block of this wavefront's share of a strip, in the batch's arrays
+    auto strip_src = [&](uint32_t strip, uint32_t &nbw) -> size_t {
         const uint32_t my = im_row0 + strip / im_strips_x, sx = strip % im_strips_x;
         const uint32_t x0 = sx * T + wave * TW; // first MCU of this wavefront
         const uint32_t nm = x0 < im_mcux ? min((uint32_t)TW, im_mcux - x0) : 0u;
         nbw = nm * BPM;
-        return P.qcoef + ((size_t)im_first_block + ((size_t)my * im_mcux + x0) * BPM) * 64u;
+        return (size_t)im_first_block + ((size_t)my * im_mcux + x0) * BPM;
     };
-    auto load3 = [&](const int16_t *src, uint32_t nbw, uint4 (&v)[NLD]) {
+    // A lane's pieces of the coefficients, and the DC values of the blocks they belong to: coefficient 0 of the arena is
+    // the DC difference as the write pass left it, the value after prediction comes from the DC array.
+    // A part of a split stream numbers its blocks from its own first one (the shift is 0 otherwise), and the MCUs of its first
+    // and last row that belong to its neighbours have no place in its DC array at all: their index is checked, not trusted.
+    const uint32_t dc_shift = im.mcu_shift * BPM, im_nblocks = im.nblocks;
+    const uint16_t *dc_img = reinterpret_cast<const uint16_t *>(P.dcabs) + im_first_block;
+    auto load3 = [&](size_t blk0, uint32_t nbw, uint4 (&v)[NLD], uint32_t &dcv) {
+        const int16_t *src = P.qcoef + blk0 * 64u;
+        const uint32_t rel0 = (uint32_t)(blk0 - im_first_block) - dc_shift; // wraps for a block before the part's first
 #pragma unroll
         for (uint32_t i = 0; i < (uint32_t)NLD; i++) {
             const uint32_t q = lane + i * 64u;
             v[i] = make_uint4(0, 0, 0, 0);
             if ((q >> 3) < nbw) v[i] = *reinterpret_cast<const uint4 *>(src + (size_t)q * 8u);
         }
+        // lane L: the DC value of the wavefront's block L
+        dcv = 0;
+        const uint32_t rel = rel0 + lane;
+        if (lane < nbw && rel < im_nblocks) dcv = dc_img[rel];
     };
+    // what lane L does with it: its block's DC term, dequantised like every other coefficient, goes over the one that the
+    // scatter of phase 1 made of the difference (natural position 0 of block L)
+    const uint32_t dc_kb = lane % BPM;
+    const uint32_t dc_q = qlds[(dc_kb < (uint32_t)(HS * VS) ? 0u : (dc_kb == (uint32_t)(HS * VS) ? 1u : 2u)) * 64u];
 
     uint4 v[NLD];
+    uint32_t dcv;
     uint32_t nbw;
     {
-        const int16_t *src = strip_src(strip0, nbw);
-        load3(src, nbw, v);
+        const size_t blk0 = strip_src(strip0, nbw);
+        load3(blk0, nbw, v, dcv);
     }
     for (uint32_t strip = strip0; strip < strip1; strip++) {
         const uint32_t my = im_row0 + strip / im_strips_x, sx = strip % im_strips_x;
@@ -1867,10 +1911,11 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
                 *reinterpret_cast<float *>(bp + off[2 * j + 1]) = (float)(int16_t)pr.y;
             }
         }
+        if (lane < (uint32_t)WB) blk[lane * ZJ_K2_BSTRIDE] = (float)(int16_t)(uint16_t)(dcv * dc_q); // (LDS stores of a wavefront land in program order)
         // fetch the next strip's coefficients now; they are consumed in the next iteration
         if (strip + 1 < strip1) {
-            const int16_t *src = strip_src(strip + 1, nbw);
-            load3(src, nbw, v);
+            const size_t blk0 = strip_src(strip + 1, nbw);
+            load3(blk0, nbw, v, dcv);
         }
         zj_wave_lds_sync();
         // phase 2: 1-D IDCT over the columns of every block, in place (src/dct.rs:104-111)
@@ -2043,6 +2088,7 @@ __device__ __forceinline__ void zj_k2_body(const ZjParams &P, const ZjImgDev &im
         // wait goes, and there it also covers the stores just issued.
 #pragma unroll
         for (int i = 0; i < NLD; i++) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
+        asm volatile("" : "+v"(dcv));
         const uint32_t xb = x0 * MW * 3u; // byte offset of the tile inside the pixel row
         const uint32_t row_valid = min((uint32_t)ROWB, (im_w - min(im_w, x0 * MW)) * 3u); // bytes inside the image
         const uint32_t rows_valid = min((uint32_t)MH, im_h - min(im_h, my * MH));
@@ -2126,8 +2172,13 @@ __global__ __launch_bounds__(256) void zj_k2_idct_gray(ZjParams P, uint32_t firs
         for (uint32_t i = 0; i < 3u; i++) {
             const uint32_t q = lane + i * 64u, b = q >> 3;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (b < nbw) v = *reinterpret_cast<const uint4 *>(src + (size_t)q * 8u);
-            const uint32_t cw[4] = {v.x, v.y, v.z, v.w};
+            uint32_t dc = 0; // the block's DC value: coefficient 0 of the arena holds the difference
+            if (b < nbw) {
+                v = *reinterpret_cast<const uint4 *>(src + (size_t)q * 8u);
+                const uint32_t rel = my * im.mcux + x0 + b - im.mcu_shift; // wraps for a block before the first of a part of a split stream
+                if (rel < im.nblocks) dc = reinterpret_cast<const uint16_t *>(P.dcabs)[im.first_block + rel];
+            }
+            const uint32_t cw[4] = {part == 0u ? ((v.x & 0xFFFF0000u) | dc) : v.x, v.y, v.z, v.w};
             char *bp = reinterpret_cast<char *>(blk + b * ZJ_K2_BSTRIDE);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -2281,6 +2332,17 @@ __global__ __launch_bounds__(256) void zj_km_scan(ZjMarkParams M)
 
 // ---------------------------------------------------------------------------------- export (tests)
 // dqcoef[b][nat] = qcoef[b][zz] * q[zz]: the reference's `blocks` entry (src/decoder.rs:237-240).
+// Coefficient 0 of every block of the arena from the DC array (the write pass leaves the difference there): for callers
+// that read the arena itself.
+__global__ __launch_bounds__(256) void zj_kx_patch_dc(ZjParams P, uint32_t nblocks)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x; // index in the DC array
+    if (g >= nblocks) return;
+    const ZjImgDev &im = P.imgs[P.blk256_img[g >> 8]];
+    const uint32_t q = g + im.mcu_shift * im.bpm; // index in the arena: the same, except in a part of a split stream
+    if (q - im.first_block < im.nblocks) P.qcoef[(size_t)q * 64u] = P.dcabs[g];
+}
+
 __global__ __launch_bounds__(256) void zj_kx_dequant(ZjParams P, uint32_t ii, int16_t *dst)
 {
     const ZjImgDev im = P.imgs[ii]; // by value: a reference would be read again after every store
@@ -2342,11 +2404,20 @@ extern "C" void zj_launch_stage1(const ZjParams &P, const ZjLaunch &L, hipStream
     if (ev) hipEventRecord(ev[e++], st);
     if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
     if (ev) hipEventRecord(ev[e++], st);
-    hipLaunchKernelGGL(zj_k1c_dcdiff, dim3((L.nblk256 + ZJ_K1C_NB - 1) / ZJ_K1C_NB), dim3(256), 0, st, P, L.nblk256);
-    zj_launch_dcscan(P, L, st);
-    if (ev) hipEventRecord(ev[e++], st);
-    hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
-    if (ev) hipEventRecord(ev[e++], st);
+    if (P.dc_in_write) {
+        // the write pass decodes the DC symbols itself and leaves the differences for the scan behind it
+        hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
+        if (ev) hipEventRecord(ev[e++], st);
+        zj_launch_dcscan(P, L, st);
+        if (ev) hipEventRecord(ev[e++], st);
+    } else {
+        // a window of MCU rows: the predictors at its first MCU need the differences of all blocks before it
+        hipLaunchKernelGGL(zj_k1c_dcdiff, dim3((L.nblk256 + ZJ_K1C_NB - 1) / ZJ_K1C_NB), dim3(256), 0, st, P, L.nblk256);
+        zj_launch_dcscan(P, L, st);
+        if (ev) hipEventRecord(ev[e++], st);
+        hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
+        if (ev) hipEventRecord(ev[e++], st);
+    }
 }
 
 // The halves of stage 1 for a part of a split stream (zj_batch_range_*): up to the block counts; from the block counts
@@ -2396,9 +2467,14 @@ extern "C" void zj_launch_stage1_tail(const ZjParams &P, const ZjLaunch &L, hipS
 {
     zj_launch_scan(P, L, st);
     if (L.nptiles) hipLaunchKernelGGL(zj_k1p_positions, dim3(L.nptiles), dim3(256), 0, st, P);
-    hipLaunchKernelGGL(zj_k1c_dcdiff, dim3((L.nblk256 + ZJ_K1C_NB - 1) / ZJ_K1C_NB), dim3(256), 0, st, P, L.nblk256);
-    zj_launch_dcscan(P, L, st);
-    hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
+    if (P.dc_in_write) {
+        hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
+        zj_launch_dcscan(P, L, st);
+    } else {
+        hipLaunchKernelGGL(zj_k1c_dcdiff, dim3((L.nblk256 + ZJ_K1C_NB - 1) / ZJ_K1C_NB), dim3(256), 0, st, P, L.nblk256);
+        zj_launch_dcscan(P, L, st);
+        hipLaunchKernelGGL(zj_k1w_write, dim3(L.nk1w), dim3(256), 0, st, P);
+    }
 }
 
 extern "C" void zj_launch_stage2(const ZjParams &P, const ZjLaunch &L, hipStream_t st, hipEvent_t *ev)
@@ -2410,6 +2486,11 @@ extern "C" void zj_launch_stage2(const ZjParams &P, const ZjLaunch &L, hipStream
     if (L.k2_count[3]) hipLaunchKernelGGL((zj_k2_idct_rgb<1, 2>), dim3(L.k2_count[3]), dim3(256), 0, st, P, L.k2_first[3]);
     if (L.k2_count[4]) hipLaunchKernelGGL(zj_k2_idct_gray, dim3(L.k2_count[4]), dim3(256), 0, st, P, L.k2_first[4]);
     if (ev) hipEventRecord(ev[0], st);
+}
+
+extern "C" void zj_launch_patch_dc(const ZjParams &P, uint32_t nblocks, hipStream_t st)
+{
+    if (nblocks) hipLaunchKernelGGL(zj_kx_patch_dc, dim3((nblocks + 255u) / 256u), dim3(256), 0, st, P, nblocks);
 }
 
 extern "C" void zj_launch_dequant(const ZjParams &P, uint32_t ii, uint32_t nblocks, int16_t *dst, hipStream_t st)

@@ -58,6 +58,7 @@ struct zj_workspace {
     // one live batch per plan slot; the workspace outlives its batches (a destroy while batches are alive is deferred to
     // the last of them)
     std::vector<zj_batch *> slot_batch;
+    zj_batch *scratch_owner; // the batch whose decode call wrote the shared scratch last: only its coefficients are there
     uint32_t live;
     bool dying;
     // per slot: pinned staging for the output pointer and pitch tables of the slot's batch (grown on demand), and the
@@ -354,6 +355,7 @@ extern "C" void zj_batch_destroy(zj_batch *b)
             ws->tables[b->ws_slot].ev_pending = b->tables_ev_pending;
         }
         if (ws->live) ws->live--;
+        if (ws->scratch_owner == b) ws->scratch_owner = nullptr;
     }
     delete b;
     if (ws && ws->dying && ws->live == 0) workspace_free(ws);
@@ -1026,7 +1028,7 @@ extern "C" zj_workspace *zj_workspace_create(zj_ctx *ctx, size_t scratch_bytes, 
     ws->stage[0] = ws->stage[1] = nullptr; ws->stage_free[0] = ws->stage_free[1] = nullptr;
     ws->stage_used[0] = ws->stage_used[1] = false;
     ws->pix_ev_valid = ws->pix_pending = false;
-    ws->live = 0; ws->dying = false;
+    ws->live = 0; ws->dying = false; ws->scratch_owner = nullptr;
     ws->slot_batch.assign(nslots, nullptr);
     ws->tables.assign(nslots, zj_workspace::SlotTables{nullptr, nullptr, nullptr, 0, nullptr, false, false});
     ws->scratch_bytes = align_up(scratch_bytes, 256);
@@ -1083,6 +1085,7 @@ static int decode_entropy(zj_batch *b)
     }
     b->entropy_launched = true;
     b->dc_patched = false;
+    if (b->scratch_pooled && b->ws) b->ws->scratch_owner = b;
     if (b->L.nchunks == 0) { // nothing to decode: the status words are all this call has to clear (otherwise stage 1's one fill does)
         if (b->n && !hip_ok(c, hipMemsetAsync(b->P.status, 0, b->n * sizeof(uint32_t), st), "memset status")) return ZJ_E_DEVICE;
         return ZJ_OK;
@@ -1275,6 +1278,7 @@ extern "C" int zj_batch_counters(zj_batch *b, uint32_t *counters)
 static bool ensure_dc_patched(zj_batch *b)
 {
     if (b->dc_patched || !b->entropy_launched || b->L.nchunks == 0) return true;
+    if (b->scratch_pooled && b->ws && b->ws->scratch_owner != b) return true; // another batch has decoded into the shared scratch since: nothing of this one is left to complete
     zj_ctx *c = b->ctx;
     if (!hip_ok(c, hipSetDevice(c->device), "hipSetDevice")) return false;
     zj_launch_patch_dc(b->P, b->L.nblk256 * 256u, c->stream);

@@ -270,6 +270,28 @@ def test_many_long_segments_scan_their_dc_values_by_segment(ctx):
     b.close()
 
 
+def test_images_of_many_chunks_in_a_batch_of_many_segments(ctx):
+    """The window scan's form for batches of 256 segments and more, on segments of ten chunks of 64 long subsequences
+    (a 4K 4:4:4 image at 64 Kbit per subsequence) beside segments of one chunk and segments that share a wavefront."""
+    import torch
+    files = [synth.encode(3840, 2160, 1, 1, 90, 0, 61, 0), synth.encode(1920, 1080, 2, 2, 90, 0, 62, 0), synth.encode(64, 48, 2, 2, 90, 0, 63, 0)]
+    refs = [oracle.decode(f) for f in files]
+    pick = [0, 2, 2, 1] + [2] * 28
+    imgs = [J.ParsedImage(files[pick[i % 32]]) for i in range(288)]
+    b = J.Batch(ctx, imgs, 65536)
+    outs = b.alloc_rgb()
+    b.decode(outs)
+    st = b.finish()
+    assert not st.any()
+    assert b.counters() == (0, 0, 0)
+    want = [torch.from_numpy(r.rgb).to("cuda:0") for r in refs]
+    for i, im in enumerate(imgs):
+        assert torch.equal(outs[i][:, : im.width * 3].reshape(im.height, im.width, 3), want[pick[i % 32]]), i
+    for i in (0, 1, 3, 256, 287):
+        assert np.array_equal(b.coefficients(i), refs[pick[i % 32]].qcoef)
+    b.close()
+
+
 def test_restart_band_equals_rows_of_full_decode(ctx):
     """The multi-GPU split of one restart-marked image: every band decoded on its own equals the same
     rows of the whole image."""

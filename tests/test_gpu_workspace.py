@@ -58,6 +58,10 @@ def test_batches_share_scratch_and_alternate(ctx):
         _check(small, is_, o1, st1, b1)  # b1 decoded last: its coefficients are the ones in the arena
         st0 = b0.finish()
         _check(big, ib, o0, st0)
+        # asking the batch that did not decode last for its coefficients is against the rules (they are gone) and must at
+        # least leave alone what is in the shared scratch now: the other batch's
+        b0.coefficients(0)
+        assert np.array_equal(b1.coefficients(1), oracle.decode(small[1]).qcoef)
         b0.decode(o0)
         st0 = b0.finish()
         _check(big, ib, o0, st0, b0)
